@@ -1,0 +1,140 @@
+/*
+ * mpc_batch.h — C-ABI of the MI355X batched SQP-RTI solver (libmpc_amd.so).
+ *
+ * Plain C, plain pointers and sizes.  This is the drop-in boundary for the
+ * reference's hot path.  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Semantics in one paragraph: a handle owns `capacity` independent OCP
+ * "capsules" (iterate x/u trajectory, multipliers pi) in device memory.  One
+ * `mpc_batch_solve*` call performs, for each of the first B capsules, exactly
+ * what one `<name>_acados_solve()` does on one capsule: one SQP-RTI step
+ * (ERK4 + forward sensitivities, LINEAR_LS Gauss-Newton cost, BGH box bounds,
+ * x0 elimination, HPIPM-style Mehrotra IPM with Riccati recursion, full step),
+ * or up to `sqp_max_iter` such steps when `sqp_max_iter > 1`.
+ */
+#ifndef MPC_BATCH_H
+#define MPC_BATCH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_NX 3 /* x, y, psi          (src/c_generated_code/acados_solver_mobile_robot.h NX) */
+#define MPC_NU 2 /* v, delta           (… NU) */
+#define MPC_NY 5 /* [x y psi v delta]  (… NY) */
+#define MPC_MAX_N 128 /* largest horizon a handle accepts (reference max is 80) */
+
+/* acados return codes reproduced per instance
+ * (acados/utils/types.h; used at src/optimizer.cpp:290-293). */
+#define MPC_SUCCESS 0
+#define MPC_NAN_DETECTED 1
+#define MPC_MAXITER 2
+#define MPC_MINSTEP 3
+#define MPC_QP_FAILURE 4
+
+/* HPIPM modes (hpipm_common.h enum hpipm_mode); the reference uses BALANCE
+ * (src/c_generated_code/acados_solver_mobile_robot.c:670). */
+#define MPC_HPIPM_SPEED_ABS 0
+#define MPC_HPIPM_SPEED 1
+#define MPC_HPIPM_BALANCE 2
+#define MPC_HPIPM_ROBUST 3
+
+/* What `<name>_acados_create()` bakes into a capsule
+ * (src/c_generated_code/acados_solver_mobile_robot.c:358-602, 608-697;
+ *  per-variant values: SURVEY.md §2.1). */
+typedef struct mpc_ocp_spec {
+    int N;            /* shooting intervals (MOBILE_ROBOT_N) */
+    double Ts;        /* time step = ERK step = cost scaling of stages 0..N-1 */
+    double L;         /* wheelbase; 0 selects the generated literals (0.27 and 3.7037037037037033) */
+    double W[5];      /* diag stage weight on [x y psi v delta] */
+    double W_e[3];    /* diag terminal weight on [x y psi] */
+    double lbu[2], ubu[2]; /* bounds on v, delta, stages 0..N-1 (idxbu = {0,1}) */
+    double lbx[2], ubx[2]; /* bounds on x, y, stages 1..N-1   (idxbx = {0,1}) */
+    int sqp_max_iter; /* 1 = SQP_RTI (the reference); >1 = repeat RTI steps until NLP residuals < nlp_tol */
+    int qp_iter_max;  /* HPIPM iter_max (50) */
+    int hpipm_mode;   /* MPC_HPIPM_BALANCE */
+    double nlp_tol;   /* used only when sqp_max_iter > 1 (reference JSON: 1e-6) */
+} mpc_ocp_spec_t;
+
+typedef struct mpc_batch mpc_batch_t; /* opaque; owns host + device memory */
+
+/* Fills `spec` with one of the reference's generated variants:
+ * "mobile_robot" (N=50), "mobile_robot_18", "mobile_robot_25",
+ * "mobile_robot_50" (N=80), "park".  Returns 0, or -1 for an unknown name.
+ * Replaces: the constants of src/c_generated_code*\/acados_solver_*.c. */
+int mpc_spec_variant(const char* name, mpc_ocp_spec_t* spec);
+
+/* Replaces mobile_robot_acados_create_capsule() + mobile_robot_acados_create()
+ * (src/c_generated_code/acados_solver_mobile_robot.c:84-111, 755-804) for
+ * `capacity` capsules at once.  `device_ids`/`n_devices` select the GPUs the
+ * batch is sharded over in contiguous slices (NULL/0 = current device).
+ * Initial iterate is all zero (acados_solver_mobile_robot.c:703-729).
+ * Returns 0, or a negative code (-1 bad argument, -2 HIP error, -3 no device). */
+int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity,
+                     const int* device_ids, int n_devices);
+
+/* Replaces the tick body of Optimizer::update_and_solve, src/optimizer.cpp:251-296:
+ *   ocp_nlp_cost_model_set(.., j, "yref", ..) for j=0..N        -> yref, yref_e
+ *   ocp_nlp_constraints_model_set(.., 0, "lbx"/"ubx", x0)       -> x0
+ *   mobile_robot_acados_solve() / mobile_robot_acados_batch_solve()
+ *       (acados_solver_mobile_robot.c:942-961)                  -> the solve
+ *   ocp_nlp_out_get(.., 0, "u", ..)                             -> u0
+ * All pointers are HOST pointers, AoS per instance as the reference stores them:
+ *   x0 [B][3], yref [B][N][5], yref_e [B][3], u0 [B][2] (out),
+ *   xtraj [B][N+1][3], utraj [B][N][2]: optional, in/out.  If non-NULL they
+ *   are loaded as the iterate before the solve (ocp_nlp_out_set "x"/"u") and
+ *   receive the new iterate afterwards; NULL keeps the handle's internal
+ *   iterate (the capsule's warm start).
+ *   status [B] (out, acados codes), qp_iter [B] (out, HPIPM iterations of the
+ *   last QP); both optional.
+ * An instance whose QP fails (status 4) keeps its previous iterate and u0 is
+ * the previous u_0, as the reference keeps u_current (src/optimizer.cpp:290-293).
+ * Blocking.  Returns 0 or a negative code. */
+int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
+                    const double* yref_e, double* u0, double* xtraj, double* utraj,
+                    int* status, int* qp_iter);
+
+/* Same call with DEVICE pointers (same AoS layouts) on the handle's first
+ * device, enqueued on `stream` (a hipStream_t, NULL = the handle's stream) and
+ * NOT synchronised: for callers that keep the batch resident in HBM (bench,
+ * Monte-Carlo drivers).  Single-device handles only.  No counterpart in the
+ * reference beyond acados_solver_mobile_robot.c:951-961. */
+int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const double* d_yref,
+                           const double* d_yref_e, double* d_u0, double* d_xtraj,
+                           double* d_utraj, int* d_status, int* d_qp_iter, void* stream);
+
+/* Replaces mobile_robot_acados_reset(capsule, 1)
+ * (acados_solver_mobile_robot.c:830-869; Optimizer::reset_solver,
+ * include/optimizer.hpp:446-456): zero x, u, pi of the selected capsules.
+ * mask [capacity] (host) selects capsules, NULL = all. */
+int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask);
+
+/* Replaces ocp_nlp_out_get(.., stage, "x"|"u"|"pi", ..) for whole trajectories
+ * (src/c_generated_code/main_mobile_robot.c:117-120).  Host pointers, any may be
+ * NULL: xtraj [B][N+1][3], utraj [B][N][2], pi [B][N][3]. */
+int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* pi);
+
+/* Replaces mobile_robot_acados_sim_solve() as used by
+ * Optimizer::integrate_next_states (src/optimizer.cpp:321-341;
+ * acados_sim_solver_mobile_robot.c:205-214): one ERK4 step of length Ts of the
+ * plant, per instance.  Host pointers x [B][3] (in/out), u [B][2]. */
+int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u);
+
+/* Replaces mobile_robot_acados_free() + free_capsule()
+ * (acados_solver_mobile_robot.c:964-993, 98-103). */
+void mpc_batch_free(mpc_batch_t* h);
+
+/* Introspection used by bench/tests: kernel time of the last solve in ms
+ * (hipEvents on the handle's stream around the device work), horizon,
+ * capacity, and the last HIP error string of this handle. */
+double mpc_batch_last_kernel_ms(mpc_batch_t* h);
+int mpc_batch_horizon(const mpc_batch_t* h);
+int mpc_batch_capacity(const mpc_batch_t* h);
+const char* mpc_batch_last_error(const mpc_batch_t* h);
+const char* mpc_batch_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_BATCH_H */

@@ -1,0 +1,902 @@
+// mpc_oracle.hpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may compile, link or call it.  libmpc_amd.so (the
+// product) contains none of it.
+//
+// PARITY STATUS: "parity unpinned" at the acados boundary.  The SQP-RTI / HPIPM
+// arithmetic of the reference lives in libacados / libhpipm / libblasfeo, which are
+// neither vendored nor pinned by the reference (README.md:35-40 clones acados master;
+// CMakeLists.txt:14-30,136) and are absent from this image.  What IS pinned:
+//   * the model functions (vde_forw / ode_fun) against the reference's own CasADi C
+//     compiled from /root/reference by oracle/Makefile into oracle/_ref/ (G1 vectors in
+//     tests/golden/, bit-exact);
+//   * the ERK4 + sensitivities against 50-digit mpmath and finite differences (G2);
+//   * the QP solution against an independent dense KKT check in numpy (G3);
+//   * the RTI fixed point against the NLP KKT conditions (G4).
+// The algorithm below restates, dense and generic, the published algorithms named at
+// each function:
+//   acados  : ocp_nlp_sqp_rti.c, sim_erk_integrator.c, ocp_nlp_cost_ls.c,
+//             ocp_nlp_constraints_bgh.c, ocp_qp_xcond_solver.c
+//   HPIPM   : ocp_qp/x_ocp_qp_ipm.c, x_ocp_qp_kkt.c, x_ocp_qp_res.c,
+//             ipm_core/x_core_qp_ipm_aux.c, x_ocp_qp_red.c
+// configured as the reference configures them
+// (src/c_generated_code/acados_solver_mobile_robot.c:140-173, 358-602, 608-697).
+//
+// It is deliberately a DIFFERENT implementation from the HIP kernels: dense
+// (nu+nx+1)x(nu+nx) square-root Riccati with a Cholesky per stage, no exploitation of
+// the model's sparsity, AoS data — so that agreement between the two is evidence.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../include/mpc_batch.h"
+
+namespace mpc_oracle {
+
+constexpr int NX = MPC_NX, NU = MPC_NU, NV = NX + NU, NB = 4, NC = 2 * NB;
+
+// ----------------------------------------------------------------------------------
+// HPIPM arguments: d_ocp_qp_ipm_arg_set_default(mode) + acados overrides.
+// Every constant that could not be re-checked against upstream offline lives here.
+// ----------------------------------------------------------------------------------
+struct IpmArg {
+    double mu0 = 1e1;
+    double alpha_min = 1e-12;
+    double res_g_max = 1e-6, res_b_max = 1e-8, res_d_max = 1e-8, res_m_max = 1e-8;
+    int iter_max = 50;  // acados qp_iter_max (acados_solver_mobile_robot.c:682)
+    int pred_corr = 1, cond_pred_corr = 1;
+    int itref_pred_max = 0, itref_corr_max = 2;
+    double reg_prim = 1e-15;
+    int lq_fact = 1;
+    double lam_min = 1e-16, t_min = 1e-16, tau_min = 1e-16;
+    double thr0 = 1e-1;          // OCP_QP_INIT_VAR cold-start threshold
+    double lq_switch_tol = 1e-5; // OCP_QP_IPM_DELTA_STEP: refactorise with LQ above this
+    double cond_pred_corr_fac = 2.0;
+    double step_scale_lo = 0.99, step_scale_hi = 0.9999999;  // UPDATE_VAR_QP
+};
+
+inline IpmArg ipm_arg_for_mode(int mode, int iter_max) {
+    IpmArg a;
+    switch (mode) {
+        case MPC_HPIPM_SPEED_ABS:
+        case MPC_HPIPM_SPEED:
+            a.res_g_max = a.res_b_max = a.res_d_max = 1e0;
+            a.res_m_max = 1e-8;
+            a.itref_corr_max = 0;
+            a.lq_fact = 0;
+            break;
+        case MPC_HPIPM_ROBUST:
+            a.mu0 = 1e2;
+            a.itref_corr_max = 4;
+            a.lq_fact = 2;
+            break;
+        case MPC_HPIPM_BALANCE:
+        default:
+            break;
+    }
+    a.iter_max = iter_max;
+    return a;
+}
+
+// ----------------------------------------------------------------------------------
+// Model.  Restates mobile_robot_expl_vde_forw / _ode_fun
+// (src/c_generated_code/mobile_robot_model/mobile_robot_expl_vde_forw.c:63-137,
+//  mobile_robot_expl_ode_fun.c:56-74), same operation order, same literals.
+// ----------------------------------------------------------------------------------
+template <class T>
+struct ModelConst {
+    T L;      // 2.7000000000000002e-01
+    T invL;   // 3.7037037037037033e+00
+};
+template <class T>
+inline ModelConst<T> model_const(double L) {
+    ModelConst<T> m;
+    if (L == 0.0 || L == 2.7000000000000002e-01) {
+        m.L = T(2.7000000000000002e-01);
+        m.invL = T(3.7037037037037033e+00);
+    } else {
+        m.L = T(L);
+        m.invL = T(1.0 / L);
+    }
+    return m;
+}
+
+template <class T>
+inline void ode_fun(const ModelConst<T>& mc, const T x[3], const T u[2], T xdot[3]) {
+    using std::cos; using std::sin; using std::tan;
+    const T v = u[0], psi = x[2];
+    xdot[0] = v * cos(psi);
+    xdot[1] = v * sin(psi);
+    xdot[2] = (v / mc.L) * tan(u[1]);
+}
+
+// Sx: 3x3 column-major, Su: 3x2 column-major.
+template <class T>
+inline void vde_forw(const ModelConst<T>& mc, const T x[3], const T Sx[9], const T Su[6],
+                     const T u[2], T xdot[3], T Sxdot[9], T Sudot[6]) {
+    using std::cos; using std::sin; using std::tan;
+    const T v = u[0], psi = x[2], delta = u[1];
+    const T c = cos(psi), s = sin(psi);
+    const T vL = v / mc.L;
+    const T tg = tan(delta);
+    xdot[0] = v * c;
+    xdot[1] = v * s;
+    xdot[2] = vL * tg;
+    for (int j = 0; j < 3; ++j) {
+        const T s2 = Sx[2 + 3 * j];
+        Sxdot[0 + 3 * j] = -(v * (s * s2));
+        Sxdot[1 + 3 * j] = v * (c * s2);
+        Sxdot[2 + 3 * j] = T(0.0);
+    }
+    {
+        const T s2 = Su[2];
+        Sudot[0] = c - v * (s * s2);
+        Sudot[1] = s + v * (c * s2);
+        Sudot[2] = mc.invL * tg;
+    }
+    {
+        const T s2 = Su[5];
+        const T cd = cos(delta);
+        Sudot[3] = -(v * (s * s2));
+        Sudot[4] = v * (c * s2);
+        Sudot[5] = vL / (cd * cd);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// ERK4, one step, forward sensitivities.  Restates acados sim_erk_integrator.c for
+// num_stages=4, num_steps=1 (acados_solver_mobile_robot.c:636-644): stage input
+// y0 + (h*a_sj)*K_j, output y0 + sum_s (h*b_s)*K_s accumulated in stage order, on the
+// 18-vector [x; vec Sx; vec Su] with S(0) = [I 0].
+// ----------------------------------------------------------------------------------
+template <class T>
+inline void erk4_forw(const ModelConst<T>& mc, T h, const T x[3], const T u[2], T xn[3],
+                      T A[9], T B[6]) {
+    constexpr int NY = 18;
+    T y0[NY], K[4][NY], ys[NY];
+    for (int i = 0; i < NY; ++i) y0[i] = T(0.0);
+    for (int i = 0; i < 3; ++i) y0[i] = x[i];
+    y0[3 + 0] = T(1.0); y0[3 + 4] = T(1.0); y0[3 + 8] = T(1.0);
+    const double a_prev[4] = {0.0, 0.5, 0.5, 1.0};  // A[s][s-1], other entries are 0
+    const double bw[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
+    for (int s = 0; s < 4; ++s) {
+        for (int i = 0; i < NY; ++i) ys[i] = y0[i];
+        if (s > 0) {
+            const T a = T(a_prev[s]) * h;
+            for (int i = 0; i < NY; ++i) ys[i] = ys[i] + a * K[s - 1][i];
+        }
+        vde_forw(mc, ys, ys + 3, ys + 12, u, K[s], K[s] + 3, K[s] + 12);
+    }
+    T y[NY];
+    for (int i = 0; i < NY; ++i) y[i] = y0[i];
+    for (int s = 0; s < 4; ++s) {
+        const T b = h * T(bw[s]);
+        for (int i = 0; i < NY; ++i) y[i] = y[i] + b * K[s][i];
+    }
+    for (int i = 0; i < 3; ++i) xn[i] = y[i];
+    for (int i = 0; i < 9; ++i) A[i] = y[3 + i];
+    for (int i = 0; i < 6; ++i) B[i] = y[12 + i];
+}
+
+// Plant step: acados sim ERK4, 1 step (acados_sim_solver_mobile_robot.c:77,138-141).
+template <class T>
+inline void erk4_plain(const ModelConst<T>& mc, T h, const T x[3], const T u[2], T xn[3]) {
+    T A[9], B[6];
+    erk4_forw(mc, h, x, u, xn, A, B);  // the sim solver integrates the same VDE
+}
+
+// ----------------------------------------------------------------------------------
+// OCP QP in HPIPM's shape (variables z_k = [u_k; x_k]).
+// ----------------------------------------------------------------------------------
+template <class T>
+struct QpStage {
+    int nu = 0, nx = 0, nb = 0, nx1 = 0;  // nx1: state dimension of the next stage
+    int idxb[NB] = {0, 0, 0, 0};
+    T H[NV * NV];    // RSQ, row-major, nv x nv
+    T g[NV];         // rq
+    T BAt[NV * NX];  // nv x nx1, row-major: row = variable, column = next state
+    T b[NX];
+    T d[NC];         // [d_lb (nb); d_ub (nb)], HPIPM sign: d_ub = -ub
+    int nv() const { return nu + nx; }
+};
+
+// One primal-dual vector of the QP; also used for steps and for residuals
+// (ux <-> res_g, pi <-> res_b, lam <-> res_d, t <-> res_m).
+template <class T>
+struct PdVec {
+    std::vector<std::array<T, NV>> ux;
+    std::vector<std::array<T, NX>> pi;
+    std::vector<std::array<T, NC>> lam, t;
+    explicit PdVec(int N = 0) { resize(N); }
+    void resize(int N) {
+        ux.assign(N + 1, {}); pi.assign(N > 0 ? N : 0, {});
+        lam.assign(N + 1, {}); t.assign(N + 1, {});
+    }
+};
+
+struct IpmStats {
+    int iter = 0;
+    int hpipm_status = 0;      // 0 success, 1 max iter, 2 min step, 3 nan
+    int lq_switch = 0;         // times the lq_fact=1 residual test asked for an LQ refactorisation
+    int itref_solves = 0;      // corrector iterative-refinement solves performed
+    int cond_pc_fallbacks = 0; // conditional predictor-corrector fell back to centering
+    double max_lin_res_fact = 0.0;  // max inf-norm of the linear-system residual after factorisation
+    double max_lin_res_corr = 0.0;  // same, first check of the corrector refinement loop
+    double res_final[4] = {0, 0, 0, 0};
+    double mu_final = 0.0;
+};
+
+template <class T>
+inline double to_double(const T& v) { return static_cast<double>(v); }
+
+template <class T>
+class OcpQpIpm {
+    int N_;
+    IpmArg arg_;
+
+  public:
+    OcpQpIpm(int N, const IpmArg& arg)
+        : N_(N), arg_(arg), qp(N + 1), sol(N), step_(N), res_(N), res_lin_(N), step_ref_(N),
+          L_(N + 1), Gamma_(N + 1), gamma_(N + 1), tinv_(N + 1), res_m_bkp_(N + 1) {}
+
+    std::vector<QpStage<T>> qp;
+    PdVec<T> sol;
+    IpmStats stats;
+
+    // HPIPM d_ocp_qp_ipm_solve (x_ocp_qp_ipm.c), cold start, delta formulation.
+    void solve() {
+        using std::fabs;
+        stats = IpmStats();
+        nc_ = 0;
+        for (int k = 0; k <= N_; ++k) nc_ += 2 * qp[k].nb;
+        init_var();
+        alpha_ = T(1.0);
+        res_compute(sol, res_, mu_);
+        backup_res_m();
+        T rn[4];
+        inf_norm(res_, rn);
+        int kk = 0;
+        force_lq_ = 0;
+        for (; kk < arg_.iter_max && to_double(alpha_) > arg_.alpha_min &&
+               (to_double(rn[0]) > arg_.res_g_max || to_double(rn[1]) > arg_.res_b_max ||
+                to_double(rn[2]) > arg_.res_d_max ||
+                std::fabs(to_double(rn[3]) - arg_.tau_min) > arg_.res_m_max);
+             ++kk) {
+            delta_step();
+            update_var();
+            res_compute(sol, res_, mu_);
+            backup_res_m();
+            inf_norm(res_, rn);
+        }
+        stats.iter = kk;
+        for (int i = 0; i < 4; ++i) stats.res_final[i] = to_double(rn[i]);
+        stats.mu_final = to_double(mu_);
+        const double mu_d = to_double(mu_);
+        if (kk == arg_.iter_max) stats.hpipm_status = 1;
+        else if (to_double(alpha_) <= arg_.alpha_min) stats.hpipm_status = 2;
+        else if (mu_d != mu_d) stats.hpipm_status = 3;
+        else stats.hpipm_status = 0;
+    }
+
+  private:
+    PdVec<T> step_, res_, res_lin_, step_ref_;
+    std::vector<std::array<T, (NV + 1) * NV>> L_;  // lower trapezoid (nv+1) x nv, row-major, ld = NV
+    std::vector<std::array<T, NC>> Gamma_, gamma_, tinv_, res_m_bkp_;
+    T mu_, mu_aff_, sigma_, alpha_, alpha_prim_, alpha_dual_;
+    int nc_ = 0, force_lq_ = 0;
+
+    // OCP_QP_INIT_VAR, warm_start = 0 (x_ocp_qp_ipm.c).
+    void init_var() {
+        const T thr0 = T(arg_.thr0), mu0 = T(arg_.mu0);
+        for (int k = 0; k <= N_; ++k) {
+            for (int i = 0; i < NV; ++i) sol.ux[k][i] = T(0.0);
+            if (k < N_) for (int i = 0; i < NX; ++i) sol.pi[k][i] = T(0.0);
+        }
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nb = s.nb;
+            for (int j = 0; j < nb; ++j) {
+                T& z = sol.ux[k][s.idxb[j]];
+                const T d_lb = s.d[j], d_ub = s.d[nb + j];
+                T t_lb = -d_lb + z;
+                T t_ub = -d_ub - z;
+                if (t_lb < thr0) {
+                    if (t_ub < thr0) {
+                        z = T(0.5) * (d_lb - d_ub);
+                        t_lb = thr0;
+                        t_ub = thr0;
+                    } else {
+                        t_lb = thr0;
+                        z = d_lb + thr0;
+                    }
+                } else if (t_ub < thr0) {
+                    t_ub = thr0;
+                    z = -d_ub - thr0;
+                }
+                sol.t[k][j] = t_lb;
+                sol.t[k][nb + j] = t_ub;
+                sol.lam[k][j] = mu0 / t_lb;
+                sol.lam[k][nb + j] = mu0 / t_ub;
+            }
+        }
+    }
+
+    // OCP_QP_RES_COMPUTE (x_ocp_qp_res.c).
+    void res_compute(const PdVec<T>& w, PdVec<T>& r, T& mu) {
+        T musum = T(0.0);
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nb = s.nb;
+            for (int i = 0; i < nv; ++i) {
+                T acc = s.g[i];
+                for (int j = 0; j < nv; ++j) acc = acc + s.H[i * NV + j] * w.ux[k][j];
+                r.ux[k][i] = acc;
+            }
+            if (k > 0)
+                for (int i = 0; i < s.nx; ++i) r.ux[k][s.nu + i] = r.ux[k][s.nu + i] - w.pi[k - 1][i];
+            for (int j = 0; j < nb; ++j) {
+                const int id = s.idxb[j];
+                r.ux[k][id] = r.ux[k][id] + (w.lam[k][nb + j] - w.lam[k][j]);
+                r.lam[k][j] = s.d[j] + w.t[k][j] - w.ux[k][id];
+                r.lam[k][nb + j] = s.d[nb + j] + w.t[k][nb + j] + w.ux[k][id];
+            }
+            if (k < N_) {
+                const int nx1 = s.nx1, nu1 = qp[k + 1].nu;
+                for (int j = 0; j < nx1; ++j) {
+                    T acc = s.b[j] - w.ux[k + 1][nu1 + j];
+                    for (int i = 0; i < nv; ++i) acc = acc + s.BAt[i * NX + j] * w.ux[k][i];
+                    r.pi[k][j] = acc;
+                }
+                for (int i = 0; i < nv; ++i) {
+                    T acc = r.ux[k][i];
+                    for (int j = 0; j < nx1; ++j) acc = acc + s.BAt[i * NX + j] * w.pi[k][j];
+                    r.ux[k][i] = acc;
+                }
+            }
+            for (int j = 0; j < 2 * nb; ++j) {
+                const T m = w.lam[k][j] * w.t[k][j];
+                musum = musum + m;
+                r.t[k][j] = m;  // qp->m is zero in acados' QP
+            }
+        }
+        mu = nc_ > 0 ? musum * T(1.0 / nc_) : T(0.0);
+    }
+
+    void backup_res_m() {
+        for (int k = 0; k <= N_; ++k)
+            for (int j = 0; j < 2 * qp[k].nb; ++j) res_m_bkp_[k][j] = res_.t[k][j];
+    }
+
+    // OCP_QP_RES_COMPUTE_INF_NORM.
+    void inf_norm(const PdVec<T>& r, T out[4]) {
+        using std::fabs;
+        T m0 = T(0.0), m1 = T(0.0), m2 = T(0.0), m3 = T(0.0);
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            for (int i = 0; i < s.nv(); ++i) { T a = fabs(r.ux[k][i]); if (!(a <= m0)) m0 = a; }
+            if (k < N_) for (int i = 0; i < s.nx1; ++i) { T a = fabs(r.pi[k][i]); if (!(a <= m1)) m1 = a; }
+            for (int j = 0; j < 2 * s.nb; ++j) {
+                T a = fabs(r.lam[k][j]); if (!(a <= m2)) m2 = a;
+                T c = fabs(r.t[k][j]); if (!(c <= m3)) m3 = c;
+            }
+        }
+        out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3;
+    }
+
+    // COMPUTE_GAMMA_GAMMA_QP / COMPUTE_GAMMA_QP (x_core_qp_ipm_aux.c).
+    void compute_Gamma_gamma(const PdVec<T>& rhs, bool with_Gamma) {
+        for (int k = 0; k <= N_; ++k)
+            for (int j = 0; j < 2 * qp[k].nb; ++j) {
+                if (with_Gamma) {
+                    tinv_[k][j] = T(1.0) / sol.t[k][j];
+                    Gamma_[k][j] = tinv_[k][j] * sol.lam[k][j];
+                }
+                gamma_[k][j] = tinv_[k][j] * (rhs.t[k][j] - sol.lam[k][j] * rhs.lam[k][j]);
+            }
+    }
+
+    // COMPUTE_LAM_T_QP after the primal step is known.
+    void compute_dlam_dt(const PdVec<T>& rhs, PdVec<T>& st) {
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nb = s.nb;
+            for (int j = 0; j < nb; ++j) {
+                st.t[k][j] = st.ux[k][s.idxb[j]];
+                st.t[k][nb + j] = -st.ux[k][s.idxb[j]];
+            }
+            for (int j = 0; j < 2 * nb; ++j) {
+                st.t[k][j] = st.t[k][j] - rhs.lam[k][j];
+                st.lam[k][j] = -tinv_[k][j] * (sol.lam[k][j] * st.t[k][j] + rhs.t[k][j]);
+            }
+        }
+    }
+
+    // BLASFEO dpotrf_l_mn semantics on a row-major (m x n) lower trapezoid, ld = NV:
+    // non-positive pivot -> that column is zeroed (inverse diagonal 0).
+    static void potrf_l_mn(int m, int n, T* M) {
+        using std::sqrt;
+        for (int j = 0; j < n; ++j) {
+            T d = M[j * NV + j];
+            for (int k = 0; k < j; ++k) d = d - M[j * NV + k] * M[j * NV + k];
+            T inv;
+            if (d > T(0.0)) { d = sqrt(d); inv = T(1.0) / d; } else { d = T(0.0); inv = T(0.0); }
+            M[j * NV + j] = d;
+            for (int i = j + 1; i < m; ++i) {
+                T v = M[i * NV + j];
+                for (int k = 0; k < j; ++k) v = v - M[i * NV + k] * M[j * NV + k];
+                M[i * NV + j] = v * inv;
+            }
+        }
+    }
+
+    // OCP_QP_FACT_SOLVE_KKT_STEP, square_root_alg = 1 (x_ocp_qp_kkt.c): backward
+    // square-root Riccati on the (nu+nx+1)x(nu+nx) trapezoid whose last row carries
+    // the gradient, then forward substitution.
+    void fact_solve_kkt_step(const PdVec<T>& rhs, PdVec<T>& st) {
+        compute_Gamma_gamma(rhs, true);
+        for (int k = N_; k >= 0; --k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nb = s.nb;
+            T* M = L_[k].data();
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j <= i; ++j) M[i * NV + j] = s.H[i * NV + j];
+            for (int i = 0; i < nv; ++i) M[i * NV + i] = M[i * NV + i] + T(arg_.reg_prim);
+            for (int j = 0; j < nv; ++j) M[nv * NV + j] = rhs.ux[k][j];
+            for (int j = 0; j < nb; ++j) {
+                const int id = s.idxb[j];
+                M[id * NV + id] = M[id * NV + id] + (Gamma_[k][j] + Gamma_[k][nb + j]);
+                M[nv * NV + id] = M[nv * NV + id] + (gamma_[k][j] - gamma_[k][nb + j]);
+            }
+            if (k < N_) {
+                const QpStage<T>& s1 = qp[k + 1];
+                const int nx1 = s.nx1, nu1 = s1.nu, nv1 = s1.nv();
+                const T* L1 = L_[k + 1].data();
+                T AL[(NV + 1) * NX];
+                // dtrmm_rlnn: AL = [BAt; b^T] * Lxx(k+1)
+                for (int i = 0; i <= nv; ++i)
+                    for (int j = 0; j < nx1; ++j) {
+                        T acc = T(0.0);
+                        for (int q = j; q < nx1; ++q) {
+                            const T lhs = (i < nv) ? s.BAt[i * NX + q] : rhs.pi[k][q];
+                            acc = acc + lhs * L1[(nu1 + q) * NV + (nu1 + j)];
+                        }
+                        AL[i * NX + j] = acc;
+                    }
+                // dgead: last row += l_x(k+1)
+                for (int j = 0; j < nx1; ++j) AL[nv * NX + j] = AL[nv * NX + j] + L1[nv1 * NV + (nu1 + j)];
+                // dsyrk_ln_mn: M += AL * AL(0:nv,:)^T
+                for (int i = 0; i <= nv; ++i)
+                    for (int j = 0; j < nv && j <= i; ++j) {
+                        T acc = M[i * NV + j];
+                        for (int q = 0; q < nx1; ++q) acc = acc + AL[i * NX + q] * AL[j * NX + q];
+                        M[i * NV + j] = acc;
+                    }
+            }
+            potrf_l_mn(nv + 1, nv, M);
+        }
+        // forward substitution
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nu = s.nu;
+            const T* Lk = L_[k].data();
+            // unknown part: the first nu entries (all nv at k = 0 where nx = 0)
+            for (int i = 0; i < nu; ++i) st.ux[k][i] = -Lk[nv * NV + i];
+            trsv_ltn_mn(nv, nu, Lk, st.ux[k].data());
+            if (k < N_) forward_dyn_and_pi(k, rhs, st, nullptr);
+        }
+        compute_dlam_dt(rhs, st);
+    }
+
+    // solve L(0:n,0:n)^T x(0:n) = x(0:n) - L(n:m,0:n)^T x(n:m)   (BLASFEO dtrsv_ltn_mn)
+    static void trsv_ltn_mn(int m, int n, const T* Lk, T* x) {
+        for (int i = n - 1; i >= 0; --i) {
+            T acc = x[i];
+            for (int q = n; q < m; ++q) acc = acc - Lk[q * NV + i] * x[q];
+            for (int q = i + 1; q < n; ++q) acc = acc - Lk[q * NV + i] * x[q];
+            x[i] = acc / Lk[i * NV + i];
+        }
+    }
+    // x(0:n) = L(0:n,0:n)^-1 x(0:n); x(n:m) -= L(n:m,0:n) x(0:n)   (BLASFEO dtrsv_lnn_mn)
+    static void trsv_lnn_mn(int m, int n, const T* Lk, T* x) {
+        for (int i = 0; i < n; ++i) {
+            T acc = x[i];
+            for (int q = 0; q < i; ++q) acc = acc - Lk[i * NV + q] * x[q];
+            x[i] = acc / Lk[i * NV + i];
+        }
+        for (int i = n; i < m; ++i) {
+            T acc = x[i];
+            for (int q = 0; q < n; ++q) acc = acc - Lk[i * NV + q] * x[q];
+            x[i] = acc;
+        }
+    }
+
+    // dx+ = BAt^T dux + b ; dpi = Lxx (Lxx^T dx+ + l_x)   [l_x from the trapezoid's last
+    // row, or p1 given explicitly by the vector-only solve]
+    void forward_dyn_and_pi(int k, const PdVec<T>& rhs, PdVec<T>& st, const T* p1) {
+        const QpStage<T>& s = qp[k];
+        const QpStage<T>& s1 = qp[k + 1];
+        const int nv = s.nv(), nx1 = s.nx1, nu1 = s1.nu, nv1 = s1.nv();
+        const T* L1 = L_[k + 1].data();
+        T dxn[NX];
+        for (int j = 0; j < nx1; ++j) {
+            T acc = rhs.pi[k][j];
+            for (int i = 0; i < nv; ++i) acc = acc + s.BAt[i * NX + j] * st.ux[k][i];
+            dxn[j] = acc;
+        }
+        T tmp[NX];
+        for (int j = 0; j < nx1; ++j) {  // Lxx^T dx+
+            T acc = T(0.0);
+            for (int q = j; q < nx1; ++q) acc = acc + L1[(nu1 + q) * NV + (nu1 + j)] * dxn[q];
+            tmp[j] = acc;
+        }
+        if (p1 == nullptr) {
+            for (int j = 0; j < nx1; ++j) tmp[j] = tmp[j] + L1[nv1 * NV + (nu1 + j)];
+            for (int i = 0; i < nx1; ++i) {  // Lxx * tmp
+                T acc = T(0.0);
+                for (int q = 0; q <= i; ++q) acc = acc + L1[(nu1 + i) * NV + (nu1 + q)] * tmp[q];
+                st.pi[k][i] = acc;
+            }
+        } else {
+            for (int i = 0; i < nx1; ++i) {
+                T acc = T(0.0);
+                for (int q = 0; q <= i; ++q) acc = acc + L1[(nu1 + i) * NV + (nu1 + q)] * tmp[q];
+                st.pi[k][i] = acc + p1[i];
+            }
+        }
+        for (int j = 0; j < nx1; ++j) st.ux[k + 1][nu1 + j] = dxn[j];
+    }
+
+    // OCP_QP_SOLVE_KKT_STEP: same factorisation, new right-hand side.
+    void solve_kkt_step(const PdVec<T>& rhs, PdVec<T>& st) {
+        compute_Gamma_gamma(rhs, false);
+        std::vector<std::array<T, NX>> pvec(N_ + 1);
+        for (int k = N_; k >= 0; --k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nb = s.nb, nu = s.nu;
+            T* v = st.ux[k].data();
+            for (int i = 0; i < nv; ++i) v[i] = rhs.ux[k][i];
+            for (int j = 0; j < nb; ++j) v[s.idxb[j]] = v[s.idxb[j]] + (gamma_[k][j] - gamma_[k][nb + j]);
+            if (k < N_) {
+                const QpStage<T>& s1 = qp[k + 1];
+                const int nx1 = s.nx1, nu1 = s1.nu;
+                const T* L1 = L_[k + 1].data();
+                T tmp[NX], Pb[NX];
+                for (int j = 0; j < nx1; ++j) {  // Lxx^T b
+                    T acc = T(0.0);
+                    for (int q = j; q < nx1; ++q) acc = acc + L1[(nu1 + q) * NV + (nu1 + j)] * rhs.pi[k][q];
+                    tmp[j] = acc;
+                }
+                for (int i = 0; i < nx1; ++i) {  // Lxx tmp + p(k+1)
+                    T acc = T(0.0);
+                    for (int q = 0; q <= i; ++q) acc = acc + L1[(nu1 + i) * NV + (nu1 + q)] * tmp[q];
+                    Pb[i] = acc + pvec[k + 1][i];
+                }
+                for (int i = 0; i < nv; ++i) {
+                    T acc = v[i];
+                    for (int j = 0; j < nx1; ++j) acc = acc + s.BAt[i * NX + j] * Pb[j];
+                    v[i] = acc;
+                }
+            }
+            trsv_lnn_mn(nv, nu, L_[k].data(), v);
+            for (int i = 0; i < s.nx; ++i) pvec[k][i] = v[nu + i];
+        }
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nu = s.nu;
+            for (int i = 0; i < nu; ++i) st.ux[k][i] = -st.ux[k][i];
+            trsv_ltn_mn(nv, nu, L_[k].data(), st.ux[k].data());
+            if (k < N_) forward_dyn_and_pi(k, rhs, st, pvec[k + 1].data());
+        }
+        compute_dlam_dt(rhs, st);
+    }
+
+    // OCP_QP_RES_COMPUTE_LIN: residual of the linearised KKT system at `st`.
+    void res_compute_lin(const PdVec<T>& rhs, const PdVec<T>& st, PdVec<T>& r) {
+        for (int k = 0; k <= N_; ++k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nb = s.nb;
+            for (int i = 0; i < nv; ++i) {
+                T acc = rhs.ux[k][i];
+                for (int j = 0; j < nv; ++j) acc = acc + s.H[i * NV + j] * st.ux[k][j];
+                r.ux[k][i] = acc;
+            }
+            if (k > 0)
+                for (int i = 0; i < s.nx; ++i) r.ux[k][s.nu + i] = r.ux[k][s.nu + i] - st.pi[k - 1][i];
+            for (int j = 0; j < nb; ++j) {
+                const int id = s.idxb[j];
+                r.ux[k][id] = r.ux[k][id] + (st.lam[k][nb + j] - st.lam[k][j]);
+                r.lam[k][j] = rhs.lam[k][j] + st.t[k][j] - st.ux[k][id];
+                r.lam[k][nb + j] = rhs.lam[k][nb + j] + st.t[k][nb + j] + st.ux[k][id];
+            }
+            if (k < N_) {
+                const int nx1 = s.nx1, nu1 = qp[k + 1].nu;
+                for (int j = 0; j < nx1; ++j) {
+                    T acc = rhs.pi[k][j] - st.ux[k + 1][nu1 + j];
+                    for (int i = 0; i < nv; ++i) acc = acc + s.BAt[i * NX + j] * st.ux[k][i];
+                    r.pi[k][j] = acc;
+                }
+                for (int i = 0; i < nv; ++i) {
+                    T acc = r.ux[k][i];
+                    for (int j = 0; j < nx1; ++j) acc = acc + s.BAt[i * NX + j] * st.pi[k][j];
+                    r.ux[k][i] = acc;
+                }
+            }
+            for (int j = 0; j < 2 * nb; ++j)
+                r.t[k][j] = rhs.t[k][j] + sol.lam[k][j] * st.t[k][j] + sol.t[k][j] * st.lam[k][j];
+        }
+    }
+
+    // COMPUTE_ALPHA_QP.
+    void compute_alpha() {
+        T alpha_prim = T(-1.0), alpha_dual = T(-1.0);
+        for (int k = 0; k <= N_; ++k)
+            for (int j = 0; j < 2 * qp[k].nb; ++j) {
+                if (alpha_dual * step_.lam[k][j] > sol.lam[k][j]) alpha_dual = sol.lam[k][j] / step_.lam[k][j];
+                if (alpha_prim * step_.t[k][j] > sol.t[k][j]) alpha_prim = sol.t[k][j] / step_.t[k][j];
+            }
+        const T alpha = alpha_prim > alpha_dual ? alpha_prim : alpha_dual;
+        alpha_prim_ = -alpha_prim;
+        alpha_dual_ = -alpha_dual;
+        alpha_ = -alpha;
+    }
+
+    // COMPUTE_MU_AFF_QP.
+    void compute_mu_aff() {
+        T mu = T(0.0);
+        for (int k = 0; k <= N_; ++k)
+            for (int j = 0; j < 2 * qp[k].nb; ++j)
+                mu = mu + (sol.lam[k][j] + alpha_ * step_.lam[k][j]) * (sol.t[k][j] + alpha_ * step_.t[k][j]);
+        mu_aff_ = mu * T(1.0 / nc_);
+    }
+
+    // COMPUTE_CENTERING_CORRECTION_QP / COMPUTE_CENTERING_QP.
+    void centering(bool with_correction) {
+        T sigma_mu = sigma_ * mu_;
+        if (!(sigma_mu > T(arg_.tau_min))) sigma_mu = T(arg_.tau_min);
+        for (int k = 0; k <= N_; ++k)
+            for (int j = 0; j < 2 * qp[k].nb; ++j) {
+                T v = res_m_bkp_[k][j];
+                if (with_correction) v = v + step_.t[k][j] * step_.lam[k][j];
+                res_.t[k][j] = v - sigma_mu;
+            }
+    }
+
+    // OCP_QP_IPM_DELTA_STEP.
+    void delta_step() {
+        fact_solve_kkt_step(res_, step_);
+        if (arg_.lq_fact == 1 && force_lq_ == 0) {
+            res_compute_lin(res_, step_, res_lin_);
+            T n[4];
+            inf_norm(res_lin_, n);
+            double worst = 0.0;
+            for (int i = 0; i < 4; ++i) { double v = to_double(n[i]); if (!(v <= worst)) worst = v; }
+            if (!(worst <= stats.max_lin_res_fact)) stats.max_lin_res_fact = worst;
+            if (!(worst <= arg_.lq_switch_tol)) {
+                // HPIPM would refactorise with the LQ-based array algorithm here (same
+                // linear system, more accurate).  Recorded, not replicated.
+                stats.lq_switch++;
+            }
+        }
+        compute_alpha();
+        if (arg_.pred_corr == 1) {
+            compute_mu_aff();
+            const T tmp = mu_aff_ / mu_;
+            sigma_ = tmp * tmp * tmp;
+            centering(true);
+            solve_kkt_step(res_, step_);
+            compute_alpha();
+            if (arg_.cond_pred_corr == 1) {
+                const T mu_aff0 = mu_aff_;
+                compute_mu_aff();
+                if (mu_aff_ > T(arg_.cond_pred_corr_fac) * mu_aff0) {
+                    stats.cond_pc_fallbacks++;
+                    centering(false);
+                    solve_kkt_step(res_, step_);
+                    compute_alpha();
+                }
+            }
+            int itref = 0;
+            for (; itref < arg_.itref_corr_max; ++itref) {
+                res_compute_lin(res_, step_, res_lin_);
+                T n[4];
+                inf_norm(res_lin_, n);
+                if (itref == 0) {
+                    double worst = 0.0;
+                    for (int i = 0; i < 4; ++i) { double v = to_double(n[i]); if (!(v <= worst)) worst = v; }
+                    if (!(worst <= stats.max_lin_res_corr)) stats.max_lin_res_corr = worst;
+                }
+                if (to_double(n[0]) < arg_.res_g_max && to_double(n[1]) < arg_.res_b_max &&
+                    to_double(n[2]) < arg_.res_d_max && to_double(n[3]) < arg_.res_m_max)
+                    break;
+                stats.itref_solves++;
+                solve_kkt_step(res_lin_, step_ref_);
+                for (int k = 0; k <= N_; ++k) {
+                    for (int i = 0; i < qp[k].nv(); ++i) step_.ux[k][i] = step_.ux[k][i] + step_ref_.ux[k][i];
+                    if (k < N_) for (int i = 0; i < qp[k].nx1; ++i) step_.pi[k][i] = step_.pi[k][i] + step_ref_.pi[k][i];
+                    for (int j = 0; j < 2 * qp[k].nb; ++j) {
+                        step_.lam[k][j] = step_.lam[k][j] + step_ref_.lam[k][j];
+                        step_.t[k][j] = step_.t[k][j] + step_ref_.t[k][j];
+                    }
+                }
+            }
+            if (itref > 0) compute_alpha();
+        }
+    }
+
+    // UPDATE_VAR_QP, split_step = 0.
+    void update_var() {
+        T alpha = alpha_;
+        if (alpha < T(1.0))
+            alpha = alpha * ((T(1.0) - alpha) * T(arg_.step_scale_lo) + alpha * T(arg_.step_scale_hi));
+        for (int k = 0; k <= N_; ++k) {
+            for (int i = 0; i < qp[k].nv(); ++i) sol.ux[k][i] = sol.ux[k][i] + alpha * step_.ux[k][i];
+            if (k < N_) for (int i = 0; i < qp[k].nx1; ++i) sol.pi[k][i] = sol.pi[k][i] + alpha * step_.pi[k][i];
+            for (int j = 0; j < 2 * qp[k].nb; ++j) {
+                sol.lam[k][j] = sol.lam[k][j] + alpha * step_.lam[k][j];
+                sol.t[k][j] = sol.t[k][j] + alpha * step_.t[k][j];
+                if (sol.lam[k][j] < T(arg_.lam_min)) sol.lam[k][j] = T(arg_.lam_min);
+                if (sol.t[k][j] < T(arg_.t_min)) sol.t[k][j] = T(arg_.t_min);
+            }
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------
+// One SQP-RTI step on one capsule.  Restates ocp_nlp_sqp_rti (preparation + feedback,
+// as_rti_level 4), with LINEAR_LS cost (ocp_nlp_cost_ls.c), BGH bounds
+// (ocp_nlp_constraints_bgh.c) and the x0 elimination done by the partial-condensing
+// wrapper (d_ocp_qp_reduce_eq_dof, x_ocp_qp_red.c); qp_cond_N = N, so no condensing
+// (acados_solver_mobile_robot.c:662-665).
+// ----------------------------------------------------------------------------------
+template <class T>
+struct RtiDebug {  // optional dump of the QP and its solution, for the G3 tests
+    std::vector<T> A, B, b, g, d;      // per stage: 9, 6, 3, 5, 8 (full-space QP incl. stage-0 x)
+    std::vector<T> dz, pi, lam, t;     // 5 per stage (N+1), 3 per stage (N), 8, 8
+};
+
+template <class T>
+struct RtiWork {
+    int N;
+    OcpQpIpm<T> ipm;
+    std::vector<T> A, B, b;  // 9N, 6N, 3N
+    RtiWork(int N_, const IpmArg& arg) : N(N_), ipm(N_, arg), A(9 * N_), B(6 * N_), b(3 * N_) {}
+};
+
+// xtraj [(N+1)*3], utraj [N*2], pi [N*3] are updated in place.  Returns acados status.
+template <class T>
+inline int rti_step(const mpc_ocp_spec_t& spec, RtiWork<T>& w, const T x0bar[3], const T* yref,
+                    const T* yref_e, T* xtraj, T* utraj, T* pi, int* qp_iter, IpmStats* stats,
+                    RtiDebug<T>* dbg = nullptr) {
+    using std::sqrt;
+    const int N = spec.N;
+    const ModelConst<T> mc = model_const<T>(spec.L);
+    const T h = T(spec.Ts);
+
+    // ---- preparation: ERK4 + sensitivities per stage (sim_erk_integrator.c) ----
+    for (int k = 0; k < N; ++k) {
+        T xn[3];
+        erk4_forw(mc, h, xtraj + 3 * k, utraj + 2 * k, xn, &w.A[9 * k], &w.B[6 * k]);
+        for (int i = 0; i < 3; ++i) w.b[3 * k + i] = xn[i] - xtraj[3 * (k + 1) + i];
+    }
+
+    // ---- LINEAR_LS Gauss-Newton blocks (ocp_nlp_cost_ls.c): W = Wc Wc^T with
+    //      Wc = chol(W) = diag(sqrt(w)); Hess = s * Cyt Wc Wc^T Cyt^T,
+    //      grad = s * Cyt Wc (Wc^T res).  Variable order [u; x]; y order [x; u].
+    T wc[5], wce[3];
+    for (int i = 0; i < 5; ++i) wc[i] = sqrt(T(spec.W[i]));
+    for (int i = 0; i < 3; ++i) wce[i] = sqrt(T(spec.W_e[i]));
+    const int y_of_var[5] = {3, 4, 0, 1, 2};  // z = [v delta x y psi] -> y index
+
+    const T dx0[3] = {x0bar[0] - xtraj[0], x0bar[1] - xtraj[1], x0bar[2] - xtraj[2]};
+
+    for (int k = 0; k <= N; ++k) {
+        QpStage<T>& s = w.ipm.qp[k];
+        std::memset(static_cast<void*>(s.H), 0, sizeof(s.H));
+        std::memset(static_cast<void*>(s.BAt), 0, sizeof(s.BAt));
+        for (int i = 0; i < NV; ++i) s.g[i] = T(0.0);
+        for (int i = 0; i < NX; ++i) s.b[i] = T(0.0);
+        for (int i = 0; i < NC; ++i) s.d[i] = T(0.0);
+        T gfull[5];
+        T hfull[5];
+        if (k < N) {
+            const T sc = h;  // cost scaling = time step (acados_solver_mobile_robot.c:380-385)
+            for (int i = 0; i < 5; ++i) {
+                const int yi = y_of_var[i];
+                const T zi = (i < 2) ? utraj[2 * k + i] : xtraj[3 * k + (i - 2)];
+                const T r = zi - yref[5 * k + yi];
+                gfull[i] = (wc[yi] * (wc[yi] * r)) * sc;
+                hfull[i] = (wc[yi] * wc[yi]) * sc;
+            }
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                const T r = xtraj[3 * N + i] - yref_e[i];
+                gfull[2 + i] = wce[i] * (wce[i] * r);  // terminal scaling 1.0
+                hfull[2 + i] = wce[i] * wce[i];
+            }
+            gfull[0] = gfull[1] = hfull[0] = hfull[1] = T(0.0);
+        }
+        if (k == 0) {
+            // x0 eliminated: variables = u_0 only; b_0 += A_0 dx0 (x_ocp_qp_red.c); the
+            // gradient picks up S^T dx0 = 0 (no cross term in this cost).
+            s.nu = 2; s.nx = 0; s.nb = 2; s.nx1 = 3;
+            s.idxb[0] = 0; s.idxb[1] = 1;
+            for (int i = 0; i < 2; ++i) { s.H[i * NV + i] = hfull[i]; s.g[i] = gfull[i]; }
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 3; ++j) s.BAt[i * NX + j] = w.B[6 * 0 + j + 3 * i];
+            for (int j = 0; j < 3; ++j) {
+                T acc = w.b[j];
+                for (int q = 0; q < 3; ++q) acc = acc + w.A[j + 3 * q] * dx0[q];
+                s.b[j] = acc;
+            }
+            for (int j = 0; j < 2; ++j) {
+                s.d[j] = T(spec.lbu[j]) - utraj[j];
+                s.d[2 + j] = utraj[j] - T(spec.ubu[j]);
+            }
+        } else if (k < N) {
+            s.nu = 2; s.nx = 3; s.nb = 4; s.nx1 = 3;
+            s.idxb[0] = 0; s.idxb[1] = 1; s.idxb[2] = 2; s.idxb[3] = 3;
+            for (int i = 0; i < 5; ++i) { s.H[i * NV + i] = hfull[i]; s.g[i] = gfull[i]; }
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 3; ++j) s.BAt[i * NX + j] = w.B[6 * k + j + 3 * i];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) s.BAt[(2 + i) * NX + j] = w.A[9 * k + j + 3 * i];
+            for (int j = 0; j < 3; ++j) s.b[j] = w.b[3 * k + j];
+            for (int j = 0; j < 2; ++j) {
+                s.d[j] = T(spec.lbu[j]) - utraj[2 * k + j];
+                s.d[4 + j] = utraj[2 * k + j] - T(spec.ubu[j]);
+                s.d[2 + j] = T(spec.lbx[j]) - xtraj[3 * k + j];
+                s.d[6 + j] = xtraj[3 * k + j] - T(spec.ubx[j]);
+            }
+        } else {
+            s.nu = 0; s.nx = 3; s.nb = 0; s.nx1 = 0;
+            for (int i = 0; i < 3; ++i) { s.H[i * NV + i] = hfull[2 + i]; s.g[i] = gfull[2 + i]; }
+        }
+    }
+
+    // ---- feedback: HPIPM IPM ----
+    w.ipm.solve();
+    if (qp_iter) *qp_iter = w.ipm.stats.iter;
+    if (stats) *stats = w.ipm.stats;
+
+    if (dbg) {
+        dbg->A = w.A; dbg->B = w.B; dbg->b = w.b;
+        dbg->g.assign(5 * (N + 1), T(0.0)); dbg->d.assign(8 * (N + 1), T(0.0));
+        dbg->dz.assign(5 * (N + 1), T(0.0)); dbg->pi.assign(3 * N, T(0.0));
+        dbg->lam.assign(8 * (N + 1), T(0.0)); dbg->t.assign(8 * (N + 1), T(0.0));
+        for (int k = 0; k <= N; ++k) {
+            const QpStage<T>& s = w.ipm.qp[k];
+            const int off = (k == N) ? 2 : 0;  // place into [u; x] slots
+            for (int i = 0; i < s.nv(); ++i) {
+                dbg->g[5 * k + off + i] = s.g[i];
+                dbg->dz[5 * k + off + i] = w.ipm.sol.ux[k][i];
+            }
+            if (k == 0) for (int i = 0; i < 3; ++i) dbg->dz[2 + i] = dx0[i];
+            for (int j = 0; j < s.nb; ++j) {
+                dbg->d[8 * k + j] = s.d[j]; dbg->d[8 * k + 4 + j] = s.d[s.nb + j];
+                dbg->lam[8 * k + j] = w.ipm.sol.lam[k][j]; dbg->lam[8 * k + 4 + j] = w.ipm.sol.lam[k][s.nb + j];
+                dbg->t[8 * k + j] = w.ipm.sol.t[k][j]; dbg->t[8 * k + 4 + j] = w.ipm.sol.t[k][s.nb + j];
+            }
+            if (k < N) for (int i = 0; i < 3; ++i) dbg->pi[3 * k + i] = w.ipm.sol.pi[k][i];
+        }
+    }
+
+    // ocp_qp_hpipm status mapping + SQP_RTI: anything but SUCCESS / MAX_ITER is a QP
+    // failure and the iterate is left untouched.
+    const int hs = w.ipm.stats.hpipm_status;
+    if (hs != 0 && hs != 1) return MPC_QP_FAILURE;
+
+    // ---- update, full step (ocp_nlp_update_variables_sqp, alpha = 1) ----
+    for (int i = 0; i < 3; ++i) xtraj[i] = xtraj[i] + dx0[i];
+    for (int k = 0; k <= N; ++k) {
+        const QpStage<T>& s = w.ipm.qp[k];
+        for (int i = 0; i < s.nu; ++i) utraj[2 * k + i] = utraj[2 * k + i] + w.ipm.sol.ux[k][i];
+        if (k > 0) for (int i = 0; i < 3; ++i) xtraj[3 * k + i] = xtraj[3 * k + i] + w.ipm.sol.ux[k][s.nu + i];
+        if (k < N && pi) for (int i = 0; i < 3; ++i) pi[3 * k + i] = w.ipm.sol.pi[k][i];
+    }
+    return MPC_SUCCESS;
+}
+
+}  // namespace mpc_oracle
