@@ -1,0 +1,171 @@
+"""ctypes binding of libmpc_amd.so (the HIP product library) — the Python caller's view of
+include/mpc_batch.h.  There is NO CPU fallback: if the library is missing or a call fails,
+this module raises.
+
+`BatchSolver` is to the C-ABI what a list of acados capsules plus
+`mobile_robot_acados_batch_solve` (src/c_generated_code/acados_solver_mobile_robot.c:951-961)
+is to the reference.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .variants import OcpSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+EXPORTS = (
+    "mpc_spec_variant", "mpc_batch_create", "mpc_batch_solve", "mpc_batch_solve_device",
+    "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
+    "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
+    "mpc_batch_last_error", "mpc_batch_version",
+)
+
+
+class MpcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmpc_amd.so (built by `make -C mpc_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpcError(f"{LIB_PATH} is missing: build it with `make -C mpc_amd/csrc` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    L.mpc_spec_variant.argtypes = [ctypes.c_char_p, ctypes.POINTER(OcpSpec)]
+    L.mpc_batch_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(OcpSpec), ctypes.c_int, _ip, ctypes.c_int]
+    L.mpc_batch_solve.argtypes = [_vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    L.mpc_batch_solve_device.argtypes = [_vp, ctypes.c_int] + [_vp] * 8 + [_vp]
+    L.mpc_batch_reset.argtypes = [_vp, ctypes.POINTER(ctypes.c_ubyte)]
+    L.mpc_batch_get.argtypes = [_vp, ctypes.c_int, _dp, _dp, _dp]
+    L.mpc_batch_sim_step.argtypes = [_vp, ctypes.c_int, _dp, _dp]
+    L.mpc_batch_free.argtypes = [_vp]
+    L.mpc_batch_free.restype = None
+    L.mpc_batch_last_kernel_ms.argtypes = [_vp]
+    L.mpc_batch_last_kernel_ms.restype = ctypes.c_double
+    L.mpc_batch_horizon.argtypes = [_vp]
+    L.mpc_batch_capacity.argtypes = [_vp]
+    L.mpc_batch_last_error.argtypes = [_vp]
+    L.mpc_batch_last_error.restype = ctypes.c_char_p
+    L.mpc_batch_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def spec_variant(name):
+    s = OcpSpec()
+    if lib().mpc_spec_variant(name.encode(), ctypes.byref(s)) != 0:
+        raise MpcError(f"unknown variant {name!r}")
+    return s
+
+
+class BatchSolver:
+    """A handle of `capacity` independent OCP capsules on one or several GPUs."""
+
+    def __init__(self, spec, capacity, devices=None):
+        self._h = _vp()
+        self.spec = spec
+        self.N = int(spec.N)
+        self.capacity = int(capacity)
+        L = lib()
+        if devices:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            rc = L.mpc_batch_create(ctypes.byref(self._h), ctypes.byref(spec), capacity, arr, len(devices))
+        else:
+            rc = L.mpc_batch_create(ctypes.byref(self._h), ctypes.byref(spec), capacity, None, 0)
+        if rc != 0:
+            self._h = _vp()
+            raise MpcError(f"mpc_batch_create failed with {rc} "
+                           "(-1 bad argument, -2 HIP error, -3 no GPU visible)")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = lib().mpc_batch_last_error(self._h)
+            raise MpcError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+    def solve(self, x0, yref, yref_e, xtraj=None, utraj=None):
+        """One SQP-RTI step per instance.  Host numpy arrays in the reference's AoS layouts.
+        Passing xtraj/utraj loads them as the iterate first (and returns the new iterate);
+        otherwise the handle's internal iterate is used, like an acados capsule."""
+        B, N = x0.shape[0], self.N
+        x0 = np.ascontiguousarray(x0, np.float64)
+        yref = np.ascontiguousarray(yref, np.float64)
+        yref_e = np.ascontiguousarray(yref_e, np.float64)
+        if x0.shape != (B, 3) or yref.shape != (B, N, 5) or yref_e.shape != (B, 3):
+            raise ValueError("expected x0 [B,3], yref [B,N,5], yref_e [B,3]")
+        xt = ut = None
+        if xtraj is not None or utraj is not None:
+            xt = np.ascontiguousarray(xtraj, np.float64).copy()
+            ut = np.ascontiguousarray(utraj, np.float64).copy()
+            if xt.shape != (B, N + 1, 3) or ut.shape != (B, N, 2):
+                raise ValueError("expected xtraj [B,N+1,3], utraj [B,N,2]")
+        u0 = np.zeros((B, 2))
+        status = np.zeros(B, np.int32)
+        it = np.zeros(B, np.int32)
+        rc = lib().mpc_batch_solve(self._h, B, _p(x0), _p(yref), _p(yref_e), _p(u0), _p(xt), _p(ut), _pi(status), _pi(it))
+        self._check(rc, "mpc_batch_solve")
+        return dict(u0=u0, xtraj=xt, utraj=ut, status=status, qp_iter=it)
+
+    def solve_device(self, B, d_x0, d_yref, d_yref_e, d_u0=0, d_xtraj=0, d_utraj=0, d_status=0, d_qp_iter=0, stream=0):
+        """Same call on raw device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        rc = lib().mpc_batch_solve_device(self._h, B, d_x0, d_yref, d_yref_e, d_u0 or None, d_xtraj or None,
+                                          d_utraj or None, d_status or None, d_qp_iter or None, stream or None)
+        self._check(rc, "mpc_batch_solve_device")
+
+    def get(self, B=None, want_pi=True):
+        B = self.capacity if B is None else B
+        N = self.N
+        xt, ut = np.zeros((B, N + 1, 3)), np.zeros((B, N, 2))
+        pi = np.zeros((B, N, 3)) if want_pi else None
+        self._check(lib().mpc_batch_get(self._h, B, _p(xt), _p(ut), _p(pi)), "mpc_batch_get")
+        return xt, ut, pi
+
+    def reset(self, mask=None):
+        if mask is None:
+            rc = lib().mpc_batch_reset(self._h, None)
+        else:
+            m = np.ascontiguousarray(mask, np.uint8)
+            if m.shape != (self.capacity,):
+                raise ValueError("mask must have one entry per capsule")
+            rc = lib().mpc_batch_reset(self._h, m.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        self._check(rc, "mpc_batch_reset")
+
+    def sim_step(self, x, u):
+        x = np.ascontiguousarray(x, np.float64).copy()
+        u = np.ascontiguousarray(u, np.float64)
+        self._check(lib().mpc_batch_sim_step(self._h, x.shape[0], _p(x), _p(u)), "mpc_batch_sim_step")
+        return x
+
+    def last_kernel_ms(self):
+        return float(lib().mpc_batch_last_kernel_ms(self._h))
+
+    def close(self):
+        if self._h:
+            lib().mpc_batch_free(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,445 @@
+// mpc_batch.hip — libmpc_amd.so: HIP kernels (gfx950) + the C-ABI of include/mpc_batch.h.
+//
+// Execution model: ONE OCP PER LANE.  A 64-lane wavefront advances 64 independent SQP-RTI
+// solves in lock-step; all per-stage data is structure-of-arrays [row][instance] in HBM so
+// every load/store of a wave is one 512-byte coalesced access.  FP64 VALU only — the 2x2 /
+// 3x3 stage blocks are not dense contractions, so no MFMA (BASELINE.json north_star).
+// The per-lane algorithm is rti_core.hpp; this file adds the batch I/O kernels (AoS <-> SoA
+// transposes through LDS), the handle, sharding over devices and the entry points.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "consts.hpp"
+
+using namespace mpc;
+
+#define MPC_WAVE 64
+
+// ------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------
+
+// One SQP-RTI step per lane (H4/H15: replaces the serial loop of
+// mobile_robot_acados_batch_solve, acados_solver_mobile_robot.c:951-961).
+__global__ __launch_bounds__(MPC_WAVE) void k_rti(Consts c, Mem m, int B, int iters) {
+    const size_t i = (size_t)blockIdx.x * MPC_WAVE + threadIdx.x;
+    if (i >= (size_t)B) return;
+    Lane lane(c, m, i);
+    for (int q = 0; q < iters; ++q) {
+        lane.rti_step();
+        if (m.STATUS[i] != 0) break;
+    }
+}
+
+// AoS [B][R] -> SoA [R][S] through a padded LDS tile (reads and writes both coalesced).
+__global__ __launch_bounds__(256) void k_aos_to_soa(const double* __restrict__ src, int R,
+                                                    double* __restrict__ dst, size_t S, int B) {
+    __shared__ double tile[32][33];
+    const int r0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    for (int yy = threadIdx.y; yy < 32; yy += 8) {
+        const int i = i0 + yy, r = r0 + threadIdx.x;
+        if (i < B && r < R) tile[yy][threadIdx.x] = src[(size_t)i * R + r];
+    }
+    __syncthreads();
+    for (int yy = threadIdx.y; yy < 32; yy += 8) {
+        const int r = r0 + yy, i = i0 + threadIdx.x;
+        if (i < B && r < R) dst[(size_t)r * S + i] = tile[threadIdx.x][yy];
+    }
+}
+
+// SoA [R][S] -> AoS [B][R].
+__global__ __launch_bounds__(256) void k_soa_to_aos(const double* __restrict__ src, size_t S, int R,
+                                                    double* __restrict__ dst, int B) {
+    __shared__ double tile[32][33];
+    const int r0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    for (int yy = threadIdx.y; yy < 32; yy += 8) {
+        const int r = r0 + yy, i = i0 + threadIdx.x;
+        if (i < B && r < R) tile[yy][threadIdx.x] = src[(size_t)r * S + i];
+    }
+    __syncthreads();
+    for (int yy = threadIdx.y; yy < 32; yy += 8) {
+        const int i = i0 + yy, r = r0 + threadIdx.x;
+        if (i < B && r < R) dst[(size_t)i * R + r] = tile[threadIdx.x][yy];
+    }
+}
+
+// H14: zero x, u, pi of the selected capsules (mobile_robot_acados_reset, :830-869).
+__global__ void k_reset(Mem m, int rowsX, int rowsU, int rowsPI, const unsigned char* mask, int cap) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)cap) return;
+    if (mask && !mask[i]) return;
+    for (int r = 0; r < rowsX; ++r) m.X[(size_t)r * m.S + i] = 0.0;
+    for (int r = 0; r < rowsU; ++r) m.U[(size_t)r * m.S + i] = 0.0;
+    for (int r = 0; r < rowsPI; ++r) m.PI[(size_t)r * m.S + i] = 0.0;
+}
+
+// H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).  x [B][3], u [B][2].
+__global__ void k_sim_step(Consts c, double* x, const double* u, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const double x0 = x[3 * i], x1 = x[3 * i + 1], psi = x[3 * i + 2];
+    const double v = u[2 * i], dl = u[2 * i + 1];
+    const double h = c.Ts;
+    const double om = (v / c.L) * tan(dl);
+    const double ah = 0.5 * h, a1 = 1.0 * h;
+    const double bw0 = h * (1.0 / 6.0), bw1 = h * (2.0 / 6.0);
+    double sA, cA, sB, cB, sD, cD;
+    sincos(psi, &sA, &cA);
+    sincos(psi + ah * om, &sB, &cB);
+    sincos(psi + a1 * om, &sD, &cD);
+    x[3 * i] = (((x0 + bw0 * (v * cA)) + bw1 * (v * cB)) + bw1 * (v * cB)) + bw0 * (v * cD);
+    x[3 * i + 1] = (((x1 + bw0 * (v * sA)) + bw1 * (v * sB)) + bw1 * (v * sB)) + bw0 * (v * sD);
+    x[3 * i + 2] = (((psi + bw0 * om) + bw1 * om) + bw1 * om) + bw0 * om;
+}
+
+// ------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------
+struct Shard {
+    int device = -1;
+    int first = 0;     // first global instance of this shard
+    int cap = 0;       // instances this shard can hold
+    size_t S = 0;      // padded stride
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* slab = nullptr;
+    int* islab = nullptr;
+    Mem mem;
+    // AoS staging for the host-pointer entry points
+    double *s_x0 = nullptr, *s_yref = nullptr, *s_yrefe = nullptr, *s_u0 = nullptr;
+    double *s_xt = nullptr, *s_ut = nullptr, *s_pi = nullptr;
+    unsigned char* s_mask = nullptr;
+};
+
+struct mpc_batch {
+    mpc_ocp_spec_t spec;
+    Consts consts;
+    int capacity = 0;
+    std::vector<Shard> shards;
+    double last_ms = 0.0;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+
+static void free_shard(Shard& s) {
+    if (s.device < 0) return;
+    (void)hipSetDevice(s.device);
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    (void)hipFree(s.slab); (void)hipFree(s.islab);
+    (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
+    (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
+    if (s.ev0) (void)hipEventDestroy(s.ev0);
+    if (s.ev1) (void)hipEventDestroy(s.ev1);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Shard();
+}
+
+static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 31) / 32); }
+
+// Enqueue the device work of one solve on shard s for its first `n` instances; all pointers
+// are device pointers in the C-ABI's AoS layouts (any of the optional ones may be null).
+static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, const double* d_yref,
+                         const double* d_yrefe, double* d_u0, double* d_xt, double* d_ut, int* d_status,
+                         int* d_iter, hipStream_t st) {
+    const int N = h->spec.N;
+    const dim3 tb(32, 8);
+    Mem& m = s.mem;
+    hipLaunchKernelGGL(k_aos_to_soa, tgrid(3, n), tb, 0, st, d_x0, 3, const_cast<double*>(m.X0), m.S, n);
+    hipLaunchKernelGGL(k_aos_to_soa, tgrid(5 * N, n), tb, 0, st, d_yref, 5 * N, const_cast<double*>(m.YREF), m.S, n);
+    hipLaunchKernelGGL(k_aos_to_soa, tgrid(3, n), tb, 0, st, d_yrefe, 3, const_cast<double*>(m.YREFE), m.S, n);
+    if (d_xt) hipLaunchKernelGGL(k_aos_to_soa, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, 3 * (N + 1), m.X, m.S, n);
+    if (d_ut) hipLaunchKernelGGL(k_aos_to_soa, tgrid(2 * N, n), tb, 0, st, d_ut, 2 * N, m.U, m.S, n);
+    const int iters = h->spec.sqp_max_iter > 1 ? h->spec.sqp_max_iter : 1;
+    hipLaunchKernelGGL(k_rti, dim3((n + MPC_WAVE - 1) / MPC_WAVE), dim3(MPC_WAVE), 0, st, h->consts, m, n, iters);
+    if (d_u0) hipLaunchKernelGGL(k_soa_to_aos, tgrid(2, n), tb, 0, st, m.U0, m.S, 2, d_u0, n);
+    if (d_xt) hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * (N + 1), n), tb, 0, st, m.X, m.S, 3 * (N + 1), d_xt, n);
+    if (d_ut) hipLaunchKernelGGL(k_soa_to_aos, tgrid(2 * N, n), tb, 0, st, m.U, m.S, 2 * N, d_ut, n);
+    if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+const char* mpc_batch_version(void) { return "mpc_amd 0.1 (gfx950, lane-per-OCP FP64)"; }
+
+int mpc_spec_variant(const char* name, mpc_ocp_spec_t* s) {
+    if (!name || !s) return -1;
+    struct Row { const char* n; int N; double Ts, W[5], We[3], lbu[2], ubu[2], lbx[2], ubx[2]; };
+    // SURVEY.md §2.1 (generated acados_solver_<name>.c of every variant)
+    static const Row rows[] = {
+        {"mobile_robot", 50, 0.05, {2, 2, 0.5, 1, 0.1}, {2, 2, 0.5}, {-0.25, -0.42}, {0.375, 0.42}, {-2, -2}, {22, 16}},
+        {"mobile_robot_18", 40, 0.125, {2, 2, 0.5, 1, 0.1}, {2, 2, 0.5}, {-0.4, -0.42}, {0.4, 0.42}, {-1, -1}, {22, 16}},
+        {"mobile_robot_25", 40, 0.1, {2, 2, 0.5, 1, 0.25}, {2, 2, 0.5}, {-1, -0.4}, {1, 0.4}, {-1, -1}, {22, 16}},
+        {"mobile_robot_50", 80, 0.05, {2, 2, 0.5, 1, 0.25}, {2, 2, 0.5}, {-1.5, -0.4}, {1.5, 0.4}, {-1, -1}, {22, 16}},
+        {"park", 49, 0.05, {1, 7, 1, 0.5, 0.05}, {1, 7, 1}, {-0.5, -0.4}, {0.5, 0.4}, {-4, -4}, {4, 4}},
+    };
+    for (const Row& r : rows) {
+        if (strcmp(name, r.n) == 0) {
+            memset(s, 0, sizeof(*s));
+            s->N = r.N; s->Ts = r.Ts; s->L = 0.0;
+            memcpy(s->W, r.W, sizeof(r.W)); memcpy(s->W_e, r.We, sizeof(r.We));
+            memcpy(s->lbu, r.lbu, sizeof(r.lbu)); memcpy(s->ubu, r.ubu, sizeof(r.ubu));
+            memcpy(s->lbx, r.lbx, sizeof(r.lbx)); memcpy(s->ubx, r.ubx, sizeof(r.ubx));
+            s->sqp_max_iter = 1; s->qp_iter_max = 50; s->hpipm_mode = MPC_HPIPM_BALANCE; s->nlp_tol = 1e-6;
+            return 0;
+        }
+    }
+    return -1;
+}
+
+int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity, const int* device_ids,
+                     int n_devices) {
+    if (!out) return -1;
+    *out = nullptr;
+    if (!spec_valid(spec) || capacity < 1) return -1;
+    int ndev_avail = 0;
+    if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail < 1) return -3;
+    std::vector<int> devs;
+    if (device_ids && n_devices > 0) {
+        for (int d = 0; d < n_devices; ++d) {
+            if (device_ids[d] < 0 || device_ids[d] >= ndev_avail) return -1;
+            devs.push_back(device_ids[d]);
+        }
+    } else {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return -3;
+        devs.push_back(cur);
+    }
+    mpc_batch* h = new mpc_batch();
+    h->spec = *spec;
+    h->consts = make_consts(*spec);
+    h->capacity = capacity;
+    const int N = spec->N;
+    const int nd = (int)devs.size();
+    const int per = (capacity + nd - 1) / nd;
+    const Rows rows = rows_for(N);
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    h->shards.resize(nd);
+    int rc = 0;
+    for (int d = 0; d < nd && rc == 0; ++d) {
+        Shard& s = h->shards[d];
+        s.device = devs[d];
+        s.first = d * per;
+        s.cap = capacity - s.first < per ? capacity - s.first : per;
+        if (s.cap < 0) s.cap = 0;
+        const int capa = s.cap > 0 ? s.cap : 1;
+        s.S = ((size_t)capa + MPC_WAVE - 1) / MPC_WAVE * MPC_WAVE;
+        auto body = [&]() -> int {
+            HIPCHK(h, hipSetDevice(s.device));
+            HIPCHK(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreate(&s.ev0));
+            HIPCHK(h, hipEventCreate(&s.ev1));
+            const size_t nd_ = (size_t)rows.total * s.S;
+            HIPCHK(h, hipMalloc(&s.slab, nd_ * sizeof(double)));
+            HIPCHK(h, hipMalloc(&s.islab, 3 * s.S * sizeof(int)));
+            HIPCHK(h, hipMemsetAsync(s.slab, 0, nd_ * sizeof(double), s.stream));
+            HIPCHK(h, hipMemsetAsync(s.islab, 0, 3 * s.S * sizeof(int), s.stream));
+            s.mem = carve(s.slab, s.islab, s.S, N);
+            HIPCHK(h, hipMalloc(&s.s_x0, sizeof(double) * 3 * capa));
+            HIPCHK(h, hipMalloc(&s.s_yref, sizeof(double) * 5 * N * capa));
+            HIPCHK(h, hipMalloc(&s.s_yrefe, sizeof(double) * 3 * capa));
+            HIPCHK(h, hipMalloc(&s.s_u0, sizeof(double) * 2 * capa));
+            HIPCHK(h, hipMalloc(&s.s_xt, sizeof(double) * 3 * (N + 1) * capa));
+            HIPCHK(h, hipMalloc(&s.s_ut, sizeof(double) * 2 * N * capa));
+            HIPCHK(h, hipMalloc(&s.s_pi, sizeof(double) * 3 * N * capa));
+            HIPCHK(h, hipMalloc(&s.s_mask, capa));
+            HIPCHK(h, hipStreamSynchronize(s.stream));
+            return 0;
+        };
+        rc = body();
+    }
+    (void)hipSetDevice(prev_dev);
+    if (rc != 0) {
+        fprintf(stderr, "mpc_batch_create: %s\n", h->err.c_str());
+        for (Shard& s : h->shards) free_shard(s);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void mpc_batch_free(mpc_batch_t* h) {
+    if (!h) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) free_shard(s);
+    (void)hipSetDevice(prev);
+    delete h;
+}
+
+int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const double* d_yref,
+                           const double* d_yref_e, double* d_u0, double* d_xtraj, double* d_utraj,
+                           int* d_status, int* d_qp_iter, void* stream) {
+    if (!h || B < 1 || B > h->capacity || !d_x0 || !d_yref || !d_yref_e) return -1;
+    if (h->shards.size() != 1) { h->err = "mpc_batch_solve_device needs a single-device handle"; return -1; }
+    Shard& s = h->shards[0];
+    hipStream_t st = stream ? (hipStream_t)stream : s.stream;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    HIPCHK(h, hipSetDevice(s.device));
+    HIPCHK(h, hipEventRecord(s.ev0, st));
+    int rc = enqueue_solve(h, s, B, d_x0, d_yref, d_yref_e, d_u0, d_xtraj, d_utraj, d_status, d_qp_iter, st);
+    if (rc == 0) HIPCHK(h, hipEventRecord(s.ev1, st));
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref, const double* yref_e,
+                    double* u0, double* xtraj, double* utraj, int* status, int* qp_iter) {
+    if (!h || B < 1 || B > h->capacity || !x0 || !yref || !yref_e) return -1;
+    if ((xtraj == nullptr) != (utraj == nullptr)) { h->err = "xtraj and utraj must be given together"; return -1; }
+    const int N = h->spec.N;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    // enqueue on every shard, then wait for all: shards run concurrently
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        const size_t o = (size_t)s.first;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipMemcpyAsync(s.s_x0, x0 + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemcpyAsync(s.s_yref, yref + 5 * N * o, sizeof(double) * 5 * N * n, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemcpyAsync(s.s_yrefe, yref_e + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+        if (xtraj) {
+            HIPCHK(h, hipMemcpyAsync(s.s_xt, xtraj + 3 * (N + 1) * o, sizeof(double) * 3 * (N + 1) * n, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(h, hipMemcpyAsync(s.s_ut, utraj + 2 * N * o, sizeof(double) * 2 * N * n, hipMemcpyHostToDevice, s.stream));
+        }
+        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+        int rc = enqueue_solve(h, s, n, s.s_x0, s.s_yref, s.s_yrefe, s.s_u0, xtraj ? s.s_xt : nullptr,
+                               xtraj ? s.s_ut : nullptr, nullptr, nullptr, s.stream);
+        if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+        if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
+        if (xtraj) {
+            HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+        }
+        if (status) HIPCHK(h, hipMemcpyAsync(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
+        if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter + o, s.mem.QPITER, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
+    }
+    double worst = 0.0;
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess && ms > worst) worst = ms;
+    }
+    h->last_ms = worst;
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
+    if (!h) return -1;
+    const int N = h->spec.N;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        if (mask) HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
+        hipLaunchKernelGGL(k_reset, dim3((s.cap + 255) / 256), dim3(256), 0, s.stream, s.mem, 3 * (N + 1), 2 * N,
+                           3 * N, mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
+        HIPCHK(h, hipGetLastError());
+    }
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* pi) {
+    if (!h || B < 1 || B > h->capacity) return -1;
+    const int N = h->spec.N;
+    const dim3 tb(32, 8);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        const size_t o = (size_t)s.first;
+        HIPCHK(h, hipSetDevice(s.device));
+        if (xtraj) {
+            hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * (N + 1), n), tb, 0, s.stream, s.mem.X, s.S, 3 * (N + 1), s.s_xt, n);
+            HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
+        }
+        if (utraj) {
+            hipLaunchKernelGGL(k_soa_to_aos, tgrid(2 * N, n), tb, 0, s.stream, s.mem.U, s.S, 2 * N, s.s_ut, n);
+            HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+        }
+        if (pi) {
+            hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * N, n), tb, 0, s.stream, s.mem.PI, s.S, 3 * N, s.s_pi, n);
+            HIPCHK(h, hipMemcpyAsync(pi + 3 * N * o, s.s_pi, sizeof(double) * 3 * N * n, hipMemcpyDeviceToHost, s.stream));
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u) {
+    if (!h || B < 1 || B > h->capacity || !x || !u) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        const size_t o = (size_t)s.first;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipMemcpyAsync(s.s_x0, x + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemcpyAsync(s.s_u0, u + 2 * o, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s.stream));
+        hipLaunchKernelGGL(k_sim_step, dim3((n + 255) / 256), dim3(256), 0, s.stream, h->consts, s.s_x0, s.s_u0, n);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(x + 3 * o, s.s_x0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s.stream));
+    }
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
+    if (!h) return -1.0;
+    if (h->shards.size() == 1) {  // device entry point: events may still be in flight
+        Shard& s = h->shards[0];
+        float ms = 0.f;
+        if (hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess)
+            h->last_ms = ms;
+    }
+    return h->last_ms;
+}
+int mpc_batch_horizon(const mpc_batch_t* h) { return h ? h->spec.N : -1; }
+int mpc_batch_capacity(const mpc_batch_t* h) { return h ? h->capacity : -1; }
+const char* mpc_batch_last_error(const mpc_batch_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+}  // extern "C"

@@ -370,17 +370,18 @@ class OcpQpIpm {
             for (int j = 0; j < 2 * qp[k].nb; ++j) res_m_bkp_[k][j] = res_.t[k][j];
     }
 
-    // OCP_QP_RES_COMPUTE_INF_NORM.
+    // OCP_QP_RES_COMPUTE_INF_NORM (BLASFEO dvecnrm_inf: norm = tmp > norm ? tmp : norm, so a
+    // NaN entry is skipped; NaNs surface through mu in the status check instead).
     void inf_norm(const PdVec<T>& r, T out[4]) {
         using std::fabs;
         T m0 = T(0.0), m1 = T(0.0), m2 = T(0.0), m3 = T(0.0);
         for (int k = 0; k <= N_; ++k) {
             const QpStage<T>& s = qp[k];
-            for (int i = 0; i < s.nv(); ++i) { T a = fabs(r.ux[k][i]); if (!(a <= m0)) m0 = a; }
-            if (k < N_) for (int i = 0; i < s.nx1; ++i) { T a = fabs(r.pi[k][i]); if (!(a <= m1)) m1 = a; }
+            for (int i = 0; i < s.nv(); ++i) { T a = fabs(r.ux[k][i]); if (a > m0) m0 = a; }
+            if (k < N_) for (int i = 0; i < s.nx1; ++i) { T a = fabs(r.pi[k][i]); if (a > m1) m1 = a; }
             for (int j = 0; j < 2 * s.nb; ++j) {
-                T a = fabs(r.lam[k][j]); if (!(a <= m2)) m2 = a;
-                T c = fabs(r.t[k][j]); if (!(c <= m3)) m3 = c;
+                T a = fabs(r.lam[k][j]); if (a > m2) m2 = a;
+                T c = fabs(r.t[k][j]); if (c > m3) m3 = c;
             }
         }
         out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3;
