@@ -35,6 +35,24 @@ class MpcError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (SONAME libamdhip64.so.7, the same as /opt/rocm's).  If libmpc_amd.so pulled in
+    /opt/rocm's copy first, a later `import torch` would load a second runtime and find no
+    GPU.  Loading torch's copy first (by path, without importing torch) makes our DT_NEEDED
+    resolve to it by SONAME; without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """Load libmpc_amd.so (built by `make -C mpc_amd/csrc` / __graft_entry__.build())."""
     global _lib
@@ -43,6 +61,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MpcError(f"{LIB_PATH} is missing: build it with `make -C mpc_amd/csrc` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     L.mpc_spec_variant.argtypes = [ctypes.c_char_p, ctypes.POINTER(OcpSpec)]
     L.mpc_batch_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(OcpSpec), ctypes.c_int, _ip, ctypes.c_int]
