@@ -1,0 +1,65 @@
+"""Multi-GPU sharding of a batch of independent OCP instances.
+
+Instances have no coupling term, so a batch is cut into contiguous slices
+[g*B/G, (g+1)*B/G), one per rank/GPU, and every rank solves its slice with no collective on
+the data path.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in CPU tests) is used
+only for the barrier around the timed region, the max-over-ranks time and the optional final
+gather of u0 (B x 2 doubles).  The reference has no counterpart: its batch entry point is a
+serial loop (src/c_generated_code/acados_solver_mobile_robot.c:951-961).
+"""
+import os
+
+import numpy as np
+
+
+def shard_range(total, world, rank):
+    """Contiguous slice of `total` instances owned by `rank` (sizes differ by at most 1)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    lo = (total * rank) // world
+    hi = (total * (rank + 1)) // world
+    return lo, hi
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend, rank, world, device=None):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if device is not None and backend == "nccl":
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def max_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local, total, device="cpu"):
+    """Optional final gather: concatenates per-rank row blocks (e.g. u0 [n_g, 2]) in rank
+    order on every rank.  Never on the critical path."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray(local)
+    world = dist.get_world_size()
+    width = local.shape[1]
+    sizes = [shard_range(total, world, r) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(nmax, width, dtype=torch.float64, device=device)
+    pad[: local.shape[0]] = torch.as_tensor(local, dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return np.concatenate([outs[r][: hi - lo].cpu().numpy() for r, (lo, hi) in enumerate(sizes)], axis=0)
