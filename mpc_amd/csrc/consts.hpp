@@ -67,36 +67,21 @@ inline Consts make_consts(const mpc_ocp_spec_t& s) {
     return c;
 }
 
-// Rows of every per-stage array (for allocation); order must match Mem.
-struct Rows {
-    int X, U, PI, X0, YREF, YREFE, AB, C, Z, PIQ, LAM, T, K, F, P, KFF, PV, RG, RB, DZA, DZ, DPI, U0;
-    int total;
-};
-inline Rows rows_for(int N) {
-    Rows r;
-    r.X = 3 * (N + 1); r.U = 2 * N; r.PI = 3 * N; r.X0 = 3; r.YREF = 5 * N; r.YREFE = 3;
-    r.AB = 8 * N; r.C = 3 * N; r.Z = 5 * (N + 1); r.PIQ = 3 * N; r.LAM = 8 * N; r.T = 8 * N;
-    r.K = 6 * N; r.F = 3 * N; r.P = 6 * N; r.KFF = 2 * N; r.PV = 3 * N; r.RG = 5 * (N + 1); r.RB = 3 * N;
-    r.DZA = 5 * (N + 1); r.DZ = 5 * (N + 1); r.DPI = 3 * N; r.U0 = 2;
-    r.total = r.X + r.U + r.PI + r.X0 + r.YREF + r.YREFE + r.AB + r.C + r.Z + r.PIQ + r.LAM + r.T + r.K +
-              r.F + r.P + r.KFF + r.PV + r.RG + r.RB + r.DZA + r.DZ + r.DPI + r.U0;
-    return r;
-}
-// Carves one slab of `total*S` doubles (+ 3*S ints) into a Mem.
-inline Mem carve(double* slab, int* islab, size_t S, int N) {
-    const Rows r = rows_for(N);
+// Workspace geometry (see the layout comment in rti_core.hpp).
+inline size_t wave_bytes_for(int N) { return (size_t)(N + 1) * MPC_RPS * 64 * sizeof(double); }
+inline size_t n_waves_for(size_t capacity) { return (capacity + 63) / 64; }
+inline size_t slab_bytes_for(int N, size_t capacity) { return n_waves_for(capacity) * wave_bytes_for(N); }
+inline Mem make_mem(char* slab, int* islab, size_t capacity, int N) {
+    const size_t S = n_waves_for(capacity) * 64;
     Mem m;
-    m.S = S;
-    double* p = slab;
-    auto take = [&](int rows) { double* q = p; p += (size_t)rows * S; return q; };
-    m.X = take(r.X); m.U = take(r.U); m.PI = take(r.PI);
-    m.X0 = take(r.X0); m.YREF = take(r.YREF); m.YREFE = take(r.YREFE);
-    m.AB = take(r.AB); m.C = take(r.C); m.Z = take(r.Z); m.PIQ = take(r.PIQ); m.LAM = take(r.LAM);
-    m.T = take(r.T); m.K = take(r.K); m.F = take(r.F); m.P = take(r.P); m.KFF = take(r.KFF);
-    m.PV = take(r.PV); m.RG = take(r.RG); m.RB = take(r.RB); m.DZA = take(r.DZA); m.DZ = take(r.DZ);
-    m.DPI = take(r.DPI); m.U0 = take(r.U0);
+    m.slab = slab;
+    m.wave_bytes = wave_bytes_for(N);
     m.STATUS = islab; m.QPITER = islab + S; m.DIAG = islab + 2 * S;
     return m;
+}
+// element (instance i, stage k, row r) as an index in doubles from the slab start
+inline size_t slab_index(const Mem& m, size_t i, int k, int r) {
+    return (i >> 6) * (m.wave_bytes / sizeof(double)) + ((size_t)(k * MPC_RPS + r) << 6) + (i & 63);
 }
 
 }  // namespace mpc

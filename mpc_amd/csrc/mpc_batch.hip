@@ -2,7 +2,7 @@
 //
 // Execution model: ONE OCP PER LANE.  A 64-lane wavefront advances 64 independent SQP-RTI
 // solves in lock-step; all per-stage data is structure-of-arrays [row][instance] in HBM so
-// every load/store of a wave is one 512-byte coalesced access.  FP64 VALU only — the 2x2 /
+// every load/store of a wave is one 512-byte coalesced access (layout: rti_core.hpp).  FP64 VALU only — the 2x2 /
 // 3x3 stage blocks are not dense contractions, so no MFMA (BASELINE.json north_star).
 // The per-lane algorithm is rti_core.hpp; this file adds the batch I/O kernels (AoS <-> SoA
 // transposes through LDS), the handle, sharding over devices and the entry points.
@@ -27,55 +27,80 @@ using namespace mpc;
 // One SQP-RTI step per lane (H4/H15: replaces the serial loop of
 // mobile_robot_acados_batch_solve, acados_solver_mobile_robot.c:951-961).
 __global__ __launch_bounds__(MPC_WAVE) void k_rti(Consts c, Mem m, int B, int iters) {
-    const size_t i = (size_t)blockIdx.x * MPC_WAVE + threadIdx.x;
-    if (i >= (size_t)B) return;
-    Lane lane(c, m, i);
+    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    const unsigned l = threadIdx.x;
+    if (wbase + l >= (size_t)B) return;
+    Lane lane(c, m, wbase, l);
     for (int q = 0; q < iters; ++q) {
         lane.rti_step();
-        if (m.STATUS[i] != 0) break;
+        if (m.STATUS[wbase + l] != 0) break;
     }
 }
 
-// AoS [B][R] -> SoA [R][S] through a padded LDS tile (reads and writes both coalesced).
-__global__ __launch_bounds__(256) void k_aos_to_soa(const double* __restrict__ src, int R,
-                                                    double* __restrict__ dst, size_t S, int B) {
-    __shared__ double tile[32][33];
-    const int r0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
-    for (int yy = threadIdx.y; yy < 32; yy += 8) {
-        const int i = i0 + yy, r = r0 + threadIdx.x;
-        if (i < B && r < R) tile[yy][threadIdx.x] = src[(size_t)i * R + r];
+// Batch I/O.  The C-ABI hands over the reference's AoS layouts; the workspace is
+// [wave][stage][row][lane].  AoS src[B][nst*ncomp] -> rows (stage kfirst+s, row roff+q), through
+// a padded LDS tile so that both the global reads (along the AoS row) and the global writes
+// (64 lanes of one workspace row) are coalesced.  grid = (ceil(R/32), n_waves), block = (32,8).
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ src, int nst, int ncomp, int kfirst,
+                                              int roff, Mem m, int B) {
+    __shared__ double tile[64][33];
+    const int R = nst * ncomp;
+    const int r0 = blockIdx.x * 32;
+    const size_t w = blockIdx.y;
+    for (int ii = threadIdx.y; ii < 64; ii += 8) {
+        const size_t i = w * 64 + ii;
+        const int r = r0 + threadIdx.x;
+        if (i < (size_t)B && r < R) tile[ii][threadIdx.x] = src[i * R + r];
     }
     __syncthreads();
-    for (int yy = threadIdx.y; yy < 32; yy += 8) {
-        const int r = r0 + yy, i = i0 + threadIdx.x;
-        if (i < B && r < R) dst[(size_t)r * S + i] = tile[threadIdx.x][yy];
+    double* blk = reinterpret_cast<double*>(m.slab + w * m.wave_bytes);
+    for (int rr = threadIdx.y; rr < 32; rr += 8) {
+        const int r = r0 + rr;
+        if (r >= R) continue;
+        const int st = r / ncomp, q = r - st * ncomp;
+        double* row = blk + ((size_t)((kfirst + st) * MPC_RPS + roff + q) << 6);
+        for (int h = 0; h < 2; ++h) {
+            const int ln = threadIdx.x + 32 * h;
+            if (w * 64 + ln < (size_t)B) row[ln] = tile[ln][rr];
+        }
     }
 }
 
-// SoA [R][S] -> AoS [B][R].
-__global__ __launch_bounds__(256) void k_soa_to_aos(const double* __restrict__ src, size_t S, int R,
-                                                    double* __restrict__ dst, int B) {
-    __shared__ double tile[32][33];
-    const int r0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
-    for (int yy = threadIdx.y; yy < 32; yy += 8) {
-        const int r = r0 + yy, i = i0 + threadIdx.x;
-        if (i < B && r < R) tile[yy][threadIdx.x] = src[(size_t)r * S + i];
+// The reverse: workspace rows -> AoS dst[B][nst*ncomp].
+__global__ __launch_bounds__(256) void k_unpack(double* __restrict__ dst, int nst, int ncomp, int kfirst, int roff,
+                                                Mem m, int B) {
+    __shared__ double tile[64][33];
+    const int R = nst * ncomp;
+    const int r0 = blockIdx.x * 32;
+    const size_t w = blockIdx.y;
+    const double* blk = reinterpret_cast<const double*>(m.slab + w * m.wave_bytes);
+    for (int rr = threadIdx.y; rr < 32; rr += 8) {
+        const int r = r0 + rr;
+        if (r >= R) continue;
+        const int st = r / ncomp, q = r - st * ncomp;
+        const double* row = blk + ((size_t)((kfirst + st) * MPC_RPS + roff + q) << 6);
+        for (int h = 0; h < 2; ++h) {
+            const int ln = threadIdx.x + 32 * h;
+            if (w * 64 + ln < (size_t)B) tile[ln][rr] = row[ln];
+        }
     }
     __syncthreads();
-    for (int yy = threadIdx.y; yy < 32; yy += 8) {
-        const int i = i0 + yy, r = r0 + threadIdx.x;
-        if (i < B && r < R) dst[(size_t)i * R + r] = tile[threadIdx.x][yy];
+    for (int ii = threadIdx.y; ii < 64; ii += 8) {
+        const size_t i = w * 64 + ii;
+        const int r = r0 + threadIdx.x;
+        if (i < (size_t)B && r < R) dst[i * R + r] = tile[ii][threadIdx.x];
     }
 }
 
 // H14: zero x, u, pi of the selected capsules (mobile_robot_acados_reset, :830-869).
-__global__ void k_reset(Mem m, int rowsX, int rowsU, int rowsPI, const unsigned char* mask, int cap) {
+__global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)cap) return;
     if (mask && !mask[i]) return;
-    for (int r = 0; r < rowsX; ++r) m.X[(size_t)r * m.S + i] = 0.0;
-    for (int r = 0; r < rowsU; ++r) m.U[(size_t)r * m.S + i] = 0.0;
-    for (int r = 0; r < rowsPI; ++r) m.PI[(size_t)r * m.S + i] = 0.0;
+    double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63);
+    for (int k = 0; k <= N; ++k)
+        for (int r = 0; r < R_YREF; ++r)  // rows R_X, R_U, R_PI are the first 8 of a stage
+            blk[(size_t)(k * MPC_RPS + r) << 6] = 0.0;
 }
 
 // H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).  x [B][3], u [B][2].
@@ -107,7 +132,7 @@ struct Shard {
     size_t S = 0;      // padded stride
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double* slab = nullptr;
+    char* slab = nullptr;
     int* islab = nullptr;
     Mem mem;
     // AoS staging for the host-pointer entry points
@@ -147,7 +172,7 @@ static void free_shard(Shard& s) {
     s = Shard();
 }
 
-static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 31) / 32); }
+static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
 
 // Enqueue the device work of one solve on shard s for its first `n` instances; all pointers
 // are device pointers in the C-ABI's AoS layouts (any of the optional ones may be null).
@@ -157,16 +182,16 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     const int N = h->spec.N;
     const dim3 tb(32, 8);
     Mem& m = s.mem;
-    hipLaunchKernelGGL(k_aos_to_soa, tgrid(3, n), tb, 0, st, d_x0, 3, const_cast<double*>(m.X0), m.S, n);
-    hipLaunchKernelGGL(k_aos_to_soa, tgrid(5 * N, n), tb, 0, st, d_yref, 5 * N, const_cast<double*>(m.YREF), m.S, n);
-    hipLaunchKernelGGL(k_aos_to_soa, tgrid(3, n), tb, 0, st, d_yrefe, 3, const_cast<double*>(m.YREFE), m.S, n);
-    if (d_xt) hipLaunchKernelGGL(k_aos_to_soa, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, 3 * (N + 1), m.X, m.S, n);
-    if (d_ut) hipLaunchKernelGGL(k_aos_to_soa, tgrid(2 * N, n), tb, 0, st, d_ut, 2 * N, m.U, m.S, n);
+    hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_x0, 1, 3, N, (int)R_X0, m, n);
+    hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
+    hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
+    if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
+    if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
     const int iters = h->spec.sqp_max_iter > 1 ? h->spec.sqp_max_iter : 1;
     hipLaunchKernelGGL(k_rti, dim3((n + MPC_WAVE - 1) / MPC_WAVE), dim3(MPC_WAVE), 0, st, h->consts, m, n, iters);
-    if (d_u0) hipLaunchKernelGGL(k_soa_to_aos, tgrid(2, n), tb, 0, st, m.U0, m.S, 2, d_u0, n);
-    if (d_xt) hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * (N + 1), n), tb, 0, st, m.X, m.S, 3 * (N + 1), d_xt, n);
-    if (d_ut) hipLaunchKernelGGL(k_soa_to_aos, tgrid(2 * N, n), tb, 0, st, m.U, m.S, 2 * N, d_ut, n);
+    if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
+    if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
+    if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
     if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
     if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipGetLastError());
@@ -227,7 +252,6 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
     const int N = spec->N;
     const int nd = (int)devs.size();
     const int per = (capacity + nd - 1) / nd;
-    const Rows rows = rows_for(N);
     int prev_dev = 0;
     (void)hipGetDevice(&prev_dev);
     h->shards.resize(nd);
@@ -245,12 +269,12 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreate(&s.ev0));
             HIPCHK(h, hipEventCreate(&s.ev1));
-            const size_t nd_ = (size_t)rows.total * s.S;
-            HIPCHK(h, hipMalloc(&s.slab, nd_ * sizeof(double)));
+            const size_t nbytes = slab_bytes_for(N, (size_t)capa);
+            HIPCHK(h, hipMalloc(&s.slab, nbytes));
             HIPCHK(h, hipMalloc(&s.islab, 3 * s.S * sizeof(int)));
-            HIPCHK(h, hipMemsetAsync(s.slab, 0, nd_ * sizeof(double), s.stream));
+            HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
             HIPCHK(h, hipMemsetAsync(s.islab, 0, 3 * s.S * sizeof(int), s.stream));
-            s.mem = carve(s.slab, s.islab, s.S, N);
+            s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
             HIPCHK(h, hipMalloc(&s.s_x0, sizeof(double) * 3 * capa));
             HIPCHK(h, hipMalloc(&s.s_yref, sizeof(double) * 5 * N * capa));
             HIPCHK(h, hipMalloc(&s.s_yrefe, sizeof(double) * 3 * capa));
@@ -357,8 +381,8 @@ int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
         if (s.cap <= 0) continue;
         HIPCHK(h, hipSetDevice(s.device));
         if (mask) HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
-        hipLaunchKernelGGL(k_reset, dim3((s.cap + 255) / 256), dim3(256), 0, s.stream, s.mem, 3 * (N + 1), 2 * N,
-                           3 * N, mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
+        hipLaunchKernelGGL(k_reset, dim3((s.cap + 255) / 256), dim3(256), 0, s.stream, s.mem, N,
+                           mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
         HIPCHK(h, hipGetLastError());
     }
     for (Shard& s : h->shards) {
@@ -382,15 +406,15 @@ int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* p
         const size_t o = (size_t)s.first;
         HIPCHK(h, hipSetDevice(s.device));
         if (xtraj) {
-            hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * (N + 1), n), tb, 0, s.stream, s.mem.X, s.S, 3 * (N + 1), s.s_xt, n);
+            hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, s.stream, s.s_xt, N + 1, 3, 0, (int)R_X, s.mem, n);
             HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
         }
         if (utraj) {
-            hipLaunchKernelGGL(k_soa_to_aos, tgrid(2 * N, n), tb, 0, s.stream, s.mem.U, s.S, 2 * N, s.s_ut, n);
+            hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, s.stream, s.s_ut, N, 2, 0, (int)R_U, s.mem, n);
             HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
         }
         if (pi) {
-            hipLaunchKernelGGL(k_soa_to_aos, tgrid(3 * N, n), tb, 0, s.stream, s.mem.PI, s.S, 3 * N, s.s_pi, n);
+            hipLaunchKernelGGL(k_unpack, tgrid(3 * N, n), tb, 0, s.stream, s.s_pi, N, 3, 0, (int)R_PI, s.mem, n);
             HIPCHK(h, hipMemcpyAsync(pi + 3 * N * o, s.s_pi, sizeof(double) * 3 * N * n, hipMemcpyDeviceToHost, s.stream));
         }
         HIPCHK(h, hipGetLastError());

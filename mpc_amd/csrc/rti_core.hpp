@@ -1,7 +1,7 @@
 // rti_core.hpp — one SQP-RTI step of the kinematic-bicycle OCP for ONE instance ("lane"),
-// written for the MI355X lane-per-OCP kernels (rti_kernels.hip).  All per-stage data lives
-// in structure-of-arrays global memory, [field][stage*comp][instance], so that the 64 lanes
-// of a wavefront read/write 64 consecutive doubles (512 B) per access.
+// written for the MI355X lane-per-OCP kernels (mpc_batch.hip).  All per-stage data lives in
+// global memory as [wave][stage][row][lane], so that the 64 lanes of a wavefront read/write
+// 64 consecutive doubles (512 B) per access and address stepping stays on the scalar unit.
 //
 // What it computes (reference file:line it replaces):
 //   linearize()   H5/H7  mobile_robot_expl_vde_forw.c:63-137 integrated by acados ERK4
@@ -10,8 +10,11 @@
 //   residuals     H8/H9  LINEAR_LS gradient/Hessian (:396-486, scaling :380-385) and BGH box
 //                        bounds (:493-580), in absolute variables zeta = z + dz
 //   x0 handling   H10    stage-0 state fixed to x0bar (idxbxe_0, :513-519)
-//   ipm_*         H11    HPIPM d_ocp_qp_ipm_solve, mode BALANCE (:670-693): Mehrotra
-//                        predictor-corrector, conditional centering fallback, Riccati
+//   sweep_*       H11    HPIPM d_ocp_qp_ipm_solve, mode BALANCE (:670-693): Mehrotra
+//                        predictor-corrector, conditional centering fallback, Riccati.
+//                        Four sequential sweeps over the stages per IPM iteration
+//                        (BU: update+residual+factorisation, FW affine, BW corrector rhs,
+//                        FW final), each software-prefetching the next stage's data.
 //   finish        H12    full-step update and status mapping of ocp_nlp_sqp_rti
 //
 // The same source compiles for the host (tests/hostbuild, test infrastructure) so that the
@@ -23,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define MPC_HD __host__ __device__ __forceinline__
+#define MPC_SWEEP __host__ __device__ __forceinline__
 #else
 #define MPC_HD inline
+#define MPC_SWEEP inline
 #endif
 
 namespace mpc {
@@ -44,22 +49,40 @@ struct Consts {
     double lq_tol;        // lin-system residual above which HPIPM would switch to LQ (diagnostic)
 };
 
-// Pointers of one handle; every array is [rows][S] with S = padded capacity.
+// Workspace layout.  One contiguous block per wavefront (64 instances):
+//     block[stage k = 0..N][row r = 0..MPC_RPS-1][lane 0..63]      (doubles)
+// so a wave's access to (k, r) is one 512-byte line group at byte offset ((k*RPS + r) << 9)
+// from the wave's block, plus lane*8.  On the GPU the block is addressed through a buffer
+// descriptor: descriptor and row offset live in SGPRs (scalar unit does the row stepping),
+// the only per-lane address register is the constant lane*8.  All data one stage visit
+// touches sits in one 40-KB span.
+enum : int {
+    R_X = 0,      // 3   capsule: state trajectory x_k
+    R_U = 3,      // 2   capsule: controls u_k
+    R_PI = 5,     // 3   capsule: multipliers of the dynamics
+    R_YREF = 8,   // 5   input: y_ref of stage k          (stage N: y_ref_e in rows 0..2)
+    R_AB = 13,    // 8   a, b, B00, B10, B20, B01, B11, B21 (stage N: x0bar rows 0..2, u0 out rows 3..4)
+    R_C = 21,     // 3   affine term of the dynamics in absolute variables
+    R_Z = 24,     // 5   zeta = z + dz  [v, delta, x, y, psi]
+    R_PIQ = 29,   // 3   QP multipliers pi
+    R_LAM = 32,   // 8   lam: lower (v, delta, x, y), upper (...)
+    R_T = 40,     // 8   slacks t, same order
+    R_P = 48,     // 6   value function P_{k+1} (sym: 00,10,11,20,21,22)
+    R_KFF = 54,   // 2   feed-forward of the current right-hand side
+    R_PV = 56,    // 3   p_{k+1}
+    R_RG = 59,    // 5   res_g
+    R_RB = 64,    // 3   res_b
+    R_DZA = 67,   // 4   affine step of the bounded variables
+    R_DZ = 71,    // 5   final step
+    R_DPI = 76,   // 3   final step of pi
+    MPC_RPS = 80, // rows per stage
+    R_YREFE = R_YREF, R_X0 = R_AB, R_U0 = R_AB + 3
+};
+
 struct Mem {
-    size_t S;
-    // capsule (persists across calls)
-    double *X, *U, *PI;            // (N+1)*3, N*2, N*3
-    // inputs of this call
-    const double *X0, *YREF, *YREFE;  // 3, N*5, 3
-    // workspace
-    double *AB, *C;                // N*8 {a,b,B00,B10,B20,B01,B11,B21}, N*3
-    double *Z, *PIQ, *LAM, *T;     // (N+1)*5, N*3, N*8, N*8
-    double *K, *F, *P, *KFF, *PV;  // N*6, N*3, N*6 (P_{k+1} at row k), N*2, N*3 (p_{k+1} at row k)
-    double *RG, *RB;               // (N+1)*5, N*3
-    double *DZA, *DZ, *DPI;        // (N+1)*5, (N+1)*5, N*3
-    // outputs
-    double* U0;                    // 2
-    int *STATUS, *QPITER, *DIAG;   // 1 each
+    char* slab;          // n_waves blocks of wave_bytes each
+    size_t wave_bytes;   // (N+1) * MPC_RPS * 512
+    int *STATUS, *QPITER, *DIAG;   // [S] each
 };
 
 #define MPC_DIAG_ITREF 1  /* HPIPM's corrector refinement test would have asked for a solve */
@@ -69,17 +92,41 @@ struct Mem {
 struct Lane {
     const Consts& c;
     const Mem& m;
-    size_t i;  // instance index
-    MPC_HD Lane(const Consts& c_, const Mem& m_, size_t i_) : c(c_), m(m_), i(i_) {}
-
-    MPC_HD double ld(const double* p, int row) const { return p[(size_t)row * m.S + i]; }
-    MPC_HD void st(double* p, int row, double v) const { p[(size_t)row * m.S + i] = v; }
+    size_t wbase;   // first instance of this wavefront (wave-uniform)
+    unsigned lane;  // threadIdx.x
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff;
+    __device__ __forceinline__ Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
+        : c(c_), m(m_), wbase(wbase_), lane(lane_) {
+        char* blk = m.slab + (wbase >> 6) * m.wave_bytes;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)m.wave_bytes, 0x00020000);
+        voff = lane_ * 8u;
+    }
+    __device__ __forceinline__ double ld(int field, int k, int comp) const {
+        const unsigned so = (unsigned)(k * MPC_RPS + field + comp) << 9;
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, so, 0));
+    }
+    __device__ __forceinline__ void st(int field, int k, int comp, double v) const {
+        const unsigned so = (unsigned)(k * MPC_RPS + field + comp) << 9;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, voff, so, 0);
+    }
+#else
+    double* blk;
+    MPC_HD Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
+        : c(c_), m(m_), wbase(wbase_), lane(lane_) {
+        blk = reinterpret_cast<double*>(m.slab + (wbase >> 6) * m.wave_bytes) + lane_;
+    }
+    MPC_HD double ld(int field, int k, int comp) const { return blk[(size_t)(k * MPC_RPS + field + comp) << 6]; }
+    MPC_HD void st(int field, int k, int comp, double v) const { blk[(size_t)(k * MPC_RPS + field + comp) << 6] = v; }
+#endif
 
     // ---- H5/H7: ERK4 with forward sensitivities, structure-exploiting but with the generic
     //      integrator's operation order (entries that are structurally 0/1 are exact there too)
     MPC_HD void linearize_stage(int k) const {
-        const double x0 = ld(m.X, 3 * k), x1 = ld(m.X, 3 * k + 1), psi = ld(m.X, 3 * k + 2);
-        const double v = ld(m.U, 2 * k), dl = ld(m.U, 2 * k + 1);
+        const double x0 = ld(R_X, k, 0), x1 = ld(R_X, k, 1), psi = ld(R_X, k, 2);
+        const double v = ld(R_U, k, 0), dl = ld(R_U, k, 1);
         const double h = c.Ts;
         const double tg = tan(dl), cd = cos(dl);
         const double vL = v / c.L;
@@ -124,13 +171,55 @@ struct Lane {
         const double B01 = (((0.0 + bw0 * k1B01) + bw1 * k2B01) + bw1 * k2B01) + bw0 * k4B01;
         const double B11 = (((0.0 + bw0 * k1B11) + bw1 * k2B11) + bw1 * k2B11) + bw0 * k4B11;
         const double B21 = (((0.0 + bw0 * s21) + bw1 * s21) + bw1 * s21) + bw0 * s21;
-        st(m.AB, 8 * k + 0, a);   st(m.AB, 8 * k + 1, b);
-        st(m.AB, 8 * k + 2, B00); st(m.AB, 8 * k + 3, B10); st(m.AB, 8 * k + 4, B20);
-        st(m.AB, 8 * k + 5, B01); st(m.AB, 8 * k + 6, B11); st(m.AB, 8 * k + 7, B21);
+        st(R_AB, k, 0, a);   st(R_AB, k, 1, b);
+        st(R_AB, k, 2, B00); st(R_AB, k, 3, B10); st(R_AB, k, 4, B20);
+        st(R_AB, k, 5, B01); st(R_AB, k, 6, B11); st(R_AB, k, 7, B21);
         // affine term of the absolute formulation: zeta_x+ = A zeta_x + B zeta_u + cvec
-        st(m.C, 3 * k + 0, xn0 - (x0 + a * psi) - (B00 * v + B01 * dl));
-        st(m.C, 3 * k + 1, xn1 - (x1 + b * psi) - (B10 * v + B11 * dl));
-        st(m.C, 3 * k + 2, xn2 - psi - (B20 * v + B21 * dl));
+        st(R_C, k, 0, xn0 - (x0 + a * psi) - (B00 * v + B01 * dl));
+        st(R_C, k, 1, xn1 - (x1 + b * psi) - (B10 * v + B11 * dl));
+        st(R_C, k, 2, xn2 - psi - (B20 * v + B21 * dl));
+    }
+
+    // ---- small value types (kept in registers) ----
+    struct AB8 { double a, b, B00, B10, B20, B01, B11, B21; };
+    struct Sym3 { double p00, p10, p11, p20, p21, p22; };
+    struct Bnd { double lam[8], t[8]; };  // [0..3] lower, [4..7] upper of (v, delta, x, y)
+
+    MPC_HD AB8 ld_ab(int k) const {
+        AB8 r;
+        r.a = ld(R_AB, k, 0); r.b = ld(R_AB, k, 1);
+        r.B00 = ld(R_AB, k, 2); r.B10 = ld(R_AB, k, 3); r.B20 = ld(R_AB, k, 4);
+        r.B01 = ld(R_AB, k, 5); r.B11 = ld(R_AB, k, 6); r.B21 = ld(R_AB, k, 7);
+        return r;
+    }
+    MPC_HD Sym3 ld_P(int k) const {
+        Sym3 r;
+        r.p00 = ld(R_P, k, 0); r.p10 = ld(R_P, k, 1); r.p11 = ld(R_P, k, 2);
+        r.p20 = ld(R_P, k, 3); r.p21 = ld(R_P, k, 4); r.p22 = ld(R_P, k, 5);
+        return r;
+    }
+    MPC_HD void st_P(int k, const Sym3& P) const {
+        st(R_P, k, 0, P.p00); st(R_P, k, 1, P.p10); st(R_P, k, 2, P.p11);
+        st(R_P, k, 3, P.p20); st(R_P, k, 4, P.p21); st(R_P, k, 5, P.p22);
+    }
+    MPC_HD Bnd ld_bnd(int k) const {
+        Bnd r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r.lam[j] = ld(R_LAM, k, j); r.t[j] = ld(R_T, k, j); }
+        return r;
+    }
+
+    // reciprocal: v_rcp_f64 + two Newton steps (what the compiler's own f64 division expands
+    // to, minus the scaling/fix-up for subnormal and huge quotients that cannot occur here)
+    MPC_HD static double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_amdgcn_rcp(x);
+        r = fma(fma(-x, r, 1.0), r, r);
+        r = fma(fma(-x, r, 1.0), r, r);
+        return r;
+#else
+        return 1.0 / x;
+#endif
     }
 
     // ---- per-constraint algebra (COMPUTE_GAMMA_GAMMA_QP / COMPUTE_LAM_T_QP) ----
@@ -140,15 +229,14 @@ struct Lane {
         double rm_l, rm_u;  // res_m (possibly corrected)
         double ti_l, ti_u;
     };
-    MPC_HD void con_load(int k, int j, double zj, Con& q) const {
-        q.lam_l = ld(m.LAM, 8 * k + j); q.lam_u = ld(m.LAM, 8 * k + 4 + j);
-        q.t_l = ld(m.T, 8 * k + j);     q.t_u = ld(m.T, 8 * k + 4 + j);
-        q.rd_l = c.lb[j] + q.t_l - zj;
-        q.rd_u = q.t_u + zj - c.ub[j];
-        q.rm_l = q.lam_l * q.t_l;
-        q.rm_u = q.lam_u * q.t_u;
-        q.ti_l = 1.0 / q.t_l;
-        q.ti_u = 1.0 / q.t_u;
+    MPC_HD void con_make(int j, double lam_l, double lam_u, double t_l, double t_u, double zj, Con& q) const {
+        q.lam_l = lam_l; q.lam_u = lam_u; q.t_l = t_l; q.t_u = t_u;
+        q.rd_l = c.lb[j] + t_l - zj;
+        q.rd_u = t_u + zj - c.ub[j];
+        q.rm_l = lam_l * t_l;
+        q.rm_u = lam_u * t_u;
+        q.ti_l = rcp(t_l);
+        q.ti_u = rcp(t_u);
     }
     // corrected complementarity residual: mode 0 = affine (lam*t), 1 = Mehrotra corrector
     // (lam*t + dt_aff*dlam_aff - sigma*mu), 2 = centering only (lam*t - sigma*mu)
@@ -177,74 +265,58 @@ struct Lane {
         s.dl_u = -q.ti_u * (q.lam_u * s.dt_u + q.rm_u);
     }
 
-    // ---- residual of stage k in forward order; pim = pi_{k-1}, pik = pi_k (0 at k = N);
-    //      z = zeta_k (5), zxn = zeta_x_{k+1}.  Writes RG/RB, returns the norms' contributions.
     struct Norms { double g, b, d, m, musum; };
     MPC_HD static double amax(double cur, double v) { const double a = fabs(v); return a > cur ? a : cur; }
 
-    MPC_HD void residual_stage(int k, const double z[5], const double zxn[3], const double pim[3],
-                               const double pik[3], Norms& n) const {
-        const int N = c.N;
-        double rg[5];
-        if (k < N) {
-            const double a = ld(m.AB, 8 * k), b = ld(m.AB, 8 * k + 1);
-            const double B00 = ld(m.AB, 8 * k + 2), B10 = ld(m.AB, 8 * k + 3), B20 = ld(m.AB, 8 * k + 4);
-            const double B01 = ld(m.AB, 8 * k + 5), B11 = ld(m.AB, 8 * k + 6), B21 = ld(m.AB, 8 * k + 7);
-            rg[0] = c.wg[0] * (z[0] - ld(m.YREF, 5 * k + 3));
-            rg[1] = c.wg[1] * (z[1] - ld(m.YREF, 5 * k + 4));
-            rg[2] = c.wg[2] * (z[2] - ld(m.YREF, 5 * k + 0)) - pim[0];
-            rg[3] = c.wg[3] * (z[3] - ld(m.YREF, 5 * k + 1)) - pim[1];
-            rg[4] = c.wg[4] * (z[4] - ld(m.YREF, 5 * k + 2)) - pim[2];
-            const int nb = (k == 0) ? 2 : 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < nb) {
-                    const double ll = ld(m.LAM, 8 * k + j), lu = ld(m.LAM, 8 * k + 4 + j);
-                    const double tl = ld(m.T, 8 * k + j), tu = ld(m.T, 8 * k + 4 + j);
-                    rg[j] += lu - ll;
-                    n.d = amax(n.d, c.lb[j] + tl - z[j]);
-                    n.d = amax(n.d, tu + z[j] - c.ub[j]);
-                    const double ml = ll * tl, mu_ = lu * tu;
-                    n.m = amax(n.m, ml);
-                    n.m = amax(n.m, mu_);
-                    n.musum += ml;
-                    n.musum += mu_;
-                }
-            }
-            // res_b = cvec + A zeta_x + B zeta_u - zeta_x+
-            const double rb0 = ld(m.C, 3 * k + 0) - zxn[0] + (B00 * z[0] + B01 * z[1] + (z[2] + a * z[4]));
-            const double rb1 = ld(m.C, 3 * k + 1) - zxn[1] + (B10 * z[0] + B11 * z[1] + (z[3] + b * z[4]));
-            const double rb2 = ld(m.C, 3 * k + 2) - zxn[2] + (B20 * z[0] + B21 * z[1] + z[4]);
-            st(m.RB, 3 * k + 0, rb0); st(m.RB, 3 * k + 1, rb1); st(m.RB, 3 * k + 2, rb2);
-            n.b = amax(n.b, rb0); n.b = amax(n.b, rb1); n.b = amax(n.b, rb2);
-            // res_g += [B A]^T pi_k
-            rg[0] += B00 * pik[0] + B10 * pik[1] + B20 * pik[2];
-            rg[1] += B01 * pik[0] + B11 * pik[1] + B21 * pik[2];
-            rg[2] += pik[0];
-            rg[3] += pik[1];
-            rg[4] += a * pik[0] + b * pik[1] + pik[2];
-        } else {
-            rg[0] = rg[1] = 0.0;
-            rg[2] = c.we[0] * (z[2] - ld(m.YREFE, 0)) - pim[0];
-            rg[3] = c.we[1] * (z[3] - ld(m.YREFE, 1)) - pim[1];
-            rg[4] = c.we[2] * (z[4] - ld(m.YREFE, 2)) - pim[2];
-        }
-        if (k < N) { n.g = amax(n.g, rg[0]); n.g = amax(n.g, rg[1]); }
-        if (k > 0) { n.g = amax(n.g, rg[2]); n.g = amax(n.g, rg[3]); n.g = amax(n.g, rg[4]); }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) st(m.RG, 5 * k + q, rg[q]);
+    // x = -(L D L^T)^-1 r for the 2x2 block
+    MPC_HD static void solve2(double id0, double l10, double id1, double r0, double r1, double& x0, double& x1) {
+        const double y1 = r1 - l10 * r0;
+        x1 = -(y1 * id1);
+        x0 = -(r0 * id0) - l10 * x1;
     }
 
-    // ---- OCP_QP_INIT_VAR (cold start) fused with the first residual evaluation ----
-    MPC_HD void init_and_residual(Norms& n) const {
+    // ---- Riccati gain of stage k from the value function P of stage k+1:
+    //      Huu = R + Gamma_u + B^T P B = L D L^T,  K = -Huu^-1 B^T P A.
+    //      Recomputed in every sweep instead of being stored (15 doubles per stage saved;
+    //      the arithmetic is identical each time, so every sweep sees the same bits).
+    struct Gain {
+        double id0, l10, id1;
+        double M00, M01, M02, M10, M11, M12;  // M = B^T P
+        double X02, X12;                      // third column of Hux = M A
+        double K00, K01, K02, K10, K11, K12;
+    };
+    MPC_HD void gain(const Sym3& P, const AB8& ab, double Gam0, double Gam1, bool needK, Gain& g) const {
+        g.M00 = ab.B00 * P.p00 + ab.B10 * P.p10 + ab.B20 * P.p20;
+        g.M01 = ab.B00 * P.p10 + ab.B10 * P.p11 + ab.B20 * P.p21;
+        g.M02 = ab.B00 * P.p20 + ab.B10 * P.p21 + ab.B20 * P.p22;
+        g.M10 = ab.B01 * P.p00 + ab.B11 * P.p10 + ab.B21 * P.p20;
+        g.M11 = ab.B01 * P.p10 + ab.B11 * P.p11 + ab.B21 * P.p21;
+        g.M12 = ab.B01 * P.p20 + ab.B11 * P.p21 + ab.B21 * P.p22;
+        const double Huu00 = (c.wg[0] + c.reg_prim) + Gam0 + (g.M00 * ab.B00 + g.M01 * ab.B10 + g.M02 * ab.B20);
+        const double Huu10 = g.M10 * ab.B00 + g.M11 * ab.B10 + g.M12 * ab.B20;
+        const double Huu11 = (c.wg[1] + c.reg_prim) + Gam1 + (g.M10 * ab.B01 + g.M11 * ab.B11 + g.M12 * ab.B21);
+        g.id0 = rcp(Huu00);
+        g.l10 = Huu10 * g.id0;
+        g.id1 = rcp(Huu11 - g.l10 * Huu10);
+        if (needK) {
+            g.X02 = g.M00 * ab.a + g.M01 * ab.b + g.M02;
+            g.X12 = g.M10 * ab.a + g.M11 * ab.b + g.M12;
+            solve2(g.id0, g.l10, g.id1, g.M00, g.M10, g.K00, g.K10);
+            solve2(g.id0, g.l10, g.id1, g.M01, g.M11, g.K01, g.K11);
+            solve2(g.id0, g.l10, g.id1, g.X02, g.X12, g.K02, g.K12);
+        }
+    }
+
+    // ---- preparation sweep (forward): ERK4 linearisation + OCP_QP_INIT_VAR cold start ----
+    MPC_SWEEP void prepare() const {
         const int N = c.N;
-        // zeta = current iterate, stage-0 state = x0bar; clip to the interior of the bounds
         for (int k = 0; k <= N; ++k) {
+            if (k < N) linearize_stage(k);
             double z[5];
-            z[0] = (k < N) ? ld(m.U, 2 * k) : 0.0;
-            z[1] = (k < N) ? ld(m.U, 2 * k + 1) : 0.0;
-            if (k == 0) { z[2] = ld(m.X0, 0); z[3] = ld(m.X0, 1); z[4] = ld(m.X0, 2); }
-            else { z[2] = ld(m.X, 3 * k); z[3] = ld(m.X, 3 * k + 1); z[4] = ld(m.X, 3 * k + 2); }
+            z[0] = (k < N) ? ld(R_U, k, 0) : 0.0;
+            z[1] = (k < N) ? ld(R_U, k, 1) : 0.0;
+            if (k == 0) { z[2] = ld(R_X0, c.N, 0); z[3] = ld(R_X0, c.N, 1); z[4] = ld(R_X0, c.N, 2); }
+            else { z[2] = ld(R_X, k, 0); z[3] = ld(R_X, k, 1); z[4] = ld(R_X, k, 2); }
             if (k < N) {
                 const int nb = (k == 0) ? 2 : 4;
 #pragma unroll
@@ -256,306 +328,393 @@ struct Lane {
                             if (tu < c.thr0) { z[j] = 0.5 * (c.lb[j] + c.ub[j]); tl = c.thr0; tu = c.thr0; }
                             else { tl = c.thr0; z[j] = c.lb[j] + c.thr0; }
                         } else if (tu < c.thr0) { tu = c.thr0; z[j] = c.ub[j] - c.thr0; }
-                        st(m.T, 8 * k + j, tl); st(m.T, 8 * k + 4 + j, tu);
-                        st(m.LAM, 8 * k + j, c.mu0 / tl); st(m.LAM, 8 * k + 4 + j, c.mu0 / tu);
+                        st(R_T, k, j, tl); st(R_T, k, 4 + j, tu);
+                        st(R_LAM, k, j, c.mu0 / tl); st(R_LAM, k, 4 + j, c.mu0 / tu);
+                    } else {  // stage 0 has no state bounds: benign values keep the unused lanes finite
+                        st(R_T, k, j, 1.0); st(R_T, k, 4 + j, 1.0);
+                        st(R_LAM, k, j, 0.0); st(R_LAM, k, 4 + j, 0.0);
                     }
                 }
-                st(m.PIQ, 3 * k, 0.0); st(m.PIQ, 3 * k + 1, 0.0); st(m.PIQ, 3 * k + 2, 0.0);
+                st(R_PIQ, k, 0, 0.0); st(R_PIQ, k, 1, 0.0); st(R_PIQ, k, 2, 0.0);
             }
 #pragma unroll
-            for (int q = 0; q < 5; ++q) st(m.Z, 5 * k + q, z[q]);
+            for (int q = 0; q < 5; ++q) st(R_Z, k, q, z[q]);
         }
-        residual_sweep(n);
     }
 
-    // residuals of all stages from the stored state (used after init; the update pass has
-    // its own fused version)
-    MPC_HD void residual_sweep(Norms& n) const {
+    // ---- sweep BU (backward): UPDATE_VAR_QP of the previous step, OCP_QP_RES_COMPUTE and the
+    //      factorisation + affine right-hand side of OCP_QP_FACT_SOLVE_KKT_STEP, fused so that
+    //      every stage's state is read and written once.  FIRST: no step to apply yet.
+    struct BuIn {
+        double z[5], dz[5], dza[4];
+        Bnd bn;
+        double pim[3], dpim[3];
+        double yref[5], cv[3];
+        AB8 ab;
+    };
+    template <bool FIRST>
+    MPC_HD void ld_bu(int k, BuIn& r) const {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r.z[q] = ld(R_Z, k, q);
+        r.bn = ld_bnd(k);
+        if (!FIRST) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r.dz[q] = ld(R_DZ, k, q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r.dza[q] = ld(R_DZA, k, q);
+        }
+        if (k > 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                r.pim[q] = ld(R_PIQ, k - 1, q);
+                if (!FIRST) r.dpim[q] = ld(R_DPI, k - 1, q);
+            }
+        } else {
+            r.pim[0] = r.pim[1] = r.pim[2] = 0.0;
+            r.dpim[0] = r.dpim[1] = r.dpim[2] = 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r.yref[q] = ld(R_YREF, k, q);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.cv[q] = ld(R_C, k, q);
+        r.ab = ld_ab(k);
+    }
+
+    template <bool FIRST>
+    MPC_SWEEP void sweep_bu(int mode, double sigma_mu, double alpha, Norms& n) const {
         const int N = c.N;
         n.g = n.b = n.d = n.m = n.musum = 0.0;
-        double pim[3] = {0.0, 0.0, 0.0};
-        double z[5];
+        // ---- terminal stage ----
+        double zxn[3], pik[3];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) z[q] = ld(m.Z, q);
-        for (int k = 0; k <= N; ++k) {
-            double zn[5] = {0, 0, 0, 0, 0}, pik[3] = {0, 0, 0};
-            if (k < N) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) zn[q] = ld(m.Z, 5 * (k + 1) + q);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) pik[q] = ld(m.PIQ, 3 * k + q);
+        for (int q = 0; q < 3; ++q) {
+            double zx = ld(R_Z, N, 2 + q);
+            double pk = ld(R_PIQ, N - 1, q);
+            if (!FIRST) {
+                zx += alpha * ld(R_DZ, N, 2 + q);
+                pk += alpha * ld(R_DPI, N - 1, q);
+                st(R_Z, N, 2 + q, zx);
+                st(R_PIQ, N - 1, q, pk);
             }
-            residual_stage(k, z, zn + 2, pim, pik, n);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) z[q] = zn[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pim[q] = pik[q];
+            zxn[q] = zx; pik[q] = pk;
         }
-    }
+        double p0 = c.we[0] * (zxn[0] - ld(R_YREFE, c.N, 0)) - pik[0];
+        double p1 = c.we[1] * (zxn[1] - ld(R_YREFE, c.N, 1)) - pik[1];
+        double p2 = c.we[2] * (zxn[2] - ld(R_YREFE, c.N, 2)) - pik[2];
+        st(R_RG, N, 2, p0); st(R_RG, N, 3, p1); st(R_RG, N, 4, p2);
+        n.g = amax(n.g, p0); n.g = amax(n.g, p1); n.g = amax(n.g, p2);
+        Sym3 P;
+        P.p00 = c.we[0] + c.reg_prim; P.p10 = 0.0; P.p11 = c.we[1] + c.reg_prim;
+        P.p20 = 0.0; P.p21 = 0.0; P.p22 = c.we[2] + c.reg_prim;
 
-    // ---- backward Riccati sweep.  mode 0: factorise + affine rhs (OCP_QP_FACT_SOLVE_KKT_STEP);
-    //      mode 1/2: rhs only with the corrected complementarity (OCP_QP_SOLVE_KKT_STEP).
-    MPC_HD void backward(int mode, double sigma_mu) const {
-        const int N = c.N;
-        // value function of stage k+1: P (sym: 00,10,11,20,21,22), p
-        double P00 = c.we[0] + c.reg_prim, P10 = 0.0, P11 = c.we[1] + c.reg_prim, P20 = 0.0, P21 = 0.0,
-               P22 = c.we[2] + c.reg_prim;
-        double p0 = ld(m.RG, 5 * N + 2), p1 = ld(m.RG, 5 * N + 3), p2 = ld(m.RG, 5 * N + 4);
+        BuIn cur, nxt;
+        ld_bu<FIRST>(N - 1, cur);
         for (int k = N - 1; k >= 0; --k) {
-            const double a = ld(m.AB, 8 * k), b = ld(m.AB, 8 * k + 1);
-            const double B00 = ld(m.AB, 8 * k + 2), B10 = ld(m.AB, 8 * k + 3), B20 = ld(m.AB, 8 * k + 4);
-            const double B01 = ld(m.AB, 8 * k + 5), B11 = ld(m.AB, 8 * k + 6), B21 = ld(m.AB, 8 * k + 7);
-            if (mode == 0) {
-                st(m.P, 6 * k + 0, P00); st(m.P, 6 * k + 1, P10); st(m.P, 6 * k + 2, P11);
-                st(m.P, 6 * k + 3, P20); st(m.P, 6 * k + 4, P21); st(m.P, 6 * k + 5, P22);
-            } else {
-                P00 = ld(m.P, 6 * k + 0); P10 = ld(m.P, 6 * k + 1); P11 = ld(m.P, 6 * k + 2);
-                P20 = ld(m.P, 6 * k + 3); P21 = ld(m.P, 6 * k + 4); P22 = ld(m.P, 6 * k + 5);
-            }
-            st(m.PV, 3 * k + 0, p0); st(m.PV, 3 * k + 1, p1); st(m.PV, 3 * k + 2, p2);
-            // w = P rb + p
-            const double rb0 = ld(m.RB, 3 * k), rb1 = ld(m.RB, 3 * k + 1), rb2 = ld(m.RB, 3 * k + 2);
-            const double w0 = P00 * rb0 + P10 * rb1 + P20 * rb2 + p0;
-            const double w1 = P10 * rb0 + P11 * rb1 + P21 * rb2 + p1;
-            const double w2 = P20 * rb0 + P21 * rb1 + P22 * rb2 + p2;
-            // constraints of this stage: Gamma (diagonal) and gamma (gradient)
+            if (k > 0) ld_bu<FIRST>(k - 1, nxt);  // software prefetch of the next stage
             const int nb = (k == 0) ? 2 : 4;
+            const AB8& ab = cur.ab;
+            // --- apply the previous step to this stage ---
+            double z[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) z[q] = FIRST ? cur.z[q] : cur.z[q] + alpha * cur.dz[q];
+            Bnd bn = cur.bn;
+            if (!FIRST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nb) {
+                        Con q;
+                        con_make(j, cur.bn.lam[j], cur.bn.lam[4 + j], cur.bn.t[j], cur.bn.t[4 + j], cur.z[j], q);
+                        con_correct(q, mode, cur.dza[j], sigma_mu);
+                        Step s;
+                        con_step(q, cur.dz[j], s);
+                        double ll = q.lam_l + alpha * s.dl_l, lu = q.lam_u + alpha * s.dl_u;
+                        double tl = q.t_l + alpha * s.dt_l, tu = q.t_u + alpha * s.dt_u;
+                        if (ll < c.lam_min) ll = c.lam_min;
+                        if (lu < c.lam_min) lu = c.lam_min;
+                        if (tl < c.t_min) tl = c.t_min;
+                        if (tu < c.t_min) tu = c.t_min;
+                        bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
+                        st(R_LAM, k, j, ll); st(R_LAM, k, 4 + j, lu);
+                        st(R_T, k, j, tl);   st(R_T, k, 4 + j, tu);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q) st(R_Z, k, q, z[q]);
+            }
+            double pim[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                pim[q] = FIRST ? cur.pim[q] : cur.pim[q] + alpha * cur.dpim[q];
+                if (!FIRST && k > 0) st(R_PIQ, k - 1, q, pim[q]);
+            }
+            // --- residuals of this stage at the new point ---
+            double rg[5];
+            rg[0] = c.wg[0] * (z[0] - cur.yref[3]);
+            rg[1] = c.wg[1] * (z[1] - cur.yref[4]);
+            rg[2] = c.wg[2] * (z[2] - cur.yref[0]) - pim[0];
+            rg[3] = c.wg[3] * (z[3] - cur.yref[1]) - pim[1];
+            rg[4] = c.wg[4] * (z[4] - cur.yref[2]) - pim[2];
             double Gam[4] = {0, 0, 0, 0}, gam[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < nb) {
                     Con q;
-                    con_load(k, j, ld(m.Z, 5 * k + j), q);
-                    if (mode != 0) con_correct(q, mode, ld(m.DZA, 5 * k + j), sigma_mu);
+                    con_make(j, bn.lam[j], bn.lam[4 + j], bn.t[j], bn.t[4 + j], z[j], q);
+                    rg[j] += q.lam_u - q.lam_l;
+                    n.d = amax(n.d, q.rd_l); n.d = amax(n.d, q.rd_u);
+                    n.m = amax(n.m, q.rm_l); n.m = amax(n.m, q.rm_u);
+                    n.musum += q.rm_l;
+                    n.musum += q.rm_u;
                     Gam[j] = con_Gamma(q);
                     gam[j] = con_gamma(q);
                 }
             }
-            // gradient
-            double hu0 = ld(m.RG, 5 * k + 0) + gam[0] + (B00 * w0 + B10 * w1 + B20 * w2);
-            double hu1 = ld(m.RG, 5 * k + 1) + gam[1] + (B01 * w0 + B11 * w1 + B21 * w2);
-            double l10, id0, id1;  // Huu = L D L^T
-            double K00, K01, K02, K10, K11, K12;
-            if (mode == 0) {
-                // M = B^T P (2x3)
-                const double M00 = B00 * P00 + B10 * P10 + B20 * P20;
-                const double M01 = B00 * P10 + B10 * P11 + B20 * P21;
-                const double M02 = B00 * P20 + B10 * P21 + B20 * P22;
-                const double M10 = B01 * P00 + B11 * P10 + B21 * P20;
-                const double M11 = B01 * P10 + B11 * P11 + B21 * P21;
-                const double M12 = B01 * P20 + B11 * P21 + B21 * P22;
-                const double Huu00 = (c.wg[0] + c.reg_prim) + Gam[0] + (M00 * B00 + M01 * B10 + M02 * B20);
-                const double Huu10 = M10 * B00 + M11 * B10 + M12 * B20;
-                const double Huu11 = (c.wg[1] + c.reg_prim) + Gam[1] + (M10 * B01 + M11 * B11 + M12 * B21);
-                id0 = 1.0 / Huu00;
-                l10 = Huu10 * id0;
-                id1 = 1.0 / (Huu11 - l10 * Huu10);
-                st(m.F, 3 * k + 0, id0); st(m.F, 3 * k + 1, l10); st(m.F, 3 * k + 2, id1);
-                if (k > 0) {
-                    // Hux = M A (2x3): columns 0,1 unchanged, column 2 = a*col0 + b*col1 + col2
-                    const double X02 = M00 * a + M01 * b + M02;
-                    const double X12 = M10 * a + M11 * b + M12;
-                    // K = -Huu^-1 Hux, column by column through L D L^T
-                    solve2(id0, l10, id1, M00, M10, K00, K10);
-                    solve2(id0, l10, id1, M01, M11, K01, K11);
-                    solve2(id0, l10, id1, X02, X12, K02, K12);
-                    st(m.K, 6 * k + 0, K00); st(m.K, 6 * k + 1, K01); st(m.K, 6 * k + 2, K02);
-                    st(m.K, 6 * k + 3, K10); st(m.K, 6 * k + 4, K11); st(m.K, 6 * k + 5, K12);
-                    // S = P A: columns 0,1 = P's, column 2 = a*P(:,0) + b*P(:,1) + P(:,2)
-                    const double S02 = P00 * a + P10 * b + P20;
-                    const double S12 = P10 * a + P11 * b + P21;
-                    const double S22 = P20 * a + P21 * b + P22;
-                    // Hxx = Q + Gamma_x + A^T S (sym); row 2 of A^T S = a*S(0,:) + b*S(1,:) + S(2,:)
-                    const double Hxx00 = (c.wg[2] + c.reg_prim) + Gam[2] + P00;
-                    const double Hxx10 = P10;
-                    const double Hxx11 = (c.wg[3] + c.reg_prim) + Gam[3] + P11;
-                    const double Hxx20 = a * P00 + b * P10 + P20;
-                    const double Hxx21 = a * P10 + b * P11 + P21;
-                    const double Hxx22 = (c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22);
-                    // P_k = Hxx + Hux^T K
-                    const double nP00 = Hxx00 + (M00 * K00 + M10 * K10);
-                    const double nP10 = Hxx10 + (M01 * K00 + M11 * K10);
-                    const double nP11 = Hxx11 + (M01 * K01 + M11 * K11);
-                    const double nP20 = Hxx20 + (X02 * K00 + X12 * K10);
-                    const double nP21 = Hxx21 + (X02 * K01 + X12 * K11);
-                    const double nP22 = Hxx22 + (X02 * K02 + X12 * K12);
-                    P00 = nP00; P10 = nP10; P11 = nP11; P20 = nP20; P21 = nP21; P22 = nP22;
-                }
-            } else {
-                id0 = ld(m.F, 3 * k + 0); l10 = ld(m.F, 3 * k + 1); id1 = ld(m.F, 3 * k + 2);
-                if (k > 0) {
-                    K00 = ld(m.K, 6 * k + 0); K01 = ld(m.K, 6 * k + 1); K02 = ld(m.K, 6 * k + 2);
-                    K10 = ld(m.K, 6 * k + 3); K11 = ld(m.K, 6 * k + 4); K12 = ld(m.K, 6 * k + 5);
-                }
-            }
+            const double rb0 = cur.cv[0] - zxn[0] + (ab.B00 * z[0] + ab.B01 * z[1] + (z[2] + ab.a * z[4]));
+            const double rb1 = cur.cv[1] - zxn[1] + (ab.B10 * z[0] + ab.B11 * z[1] + (z[3] + ab.b * z[4]));
+            const double rb2 = cur.cv[2] - zxn[2] + (ab.B20 * z[0] + ab.B21 * z[1] + z[4]);
+            st(R_RB, k, 0, rb0); st(R_RB, k, 1, rb1); st(R_RB, k, 2, rb2);
+            n.b = amax(n.b, rb0); n.b = amax(n.b, rb1); n.b = amax(n.b, rb2);
+            rg[0] += ab.B00 * pik[0] + ab.B10 * pik[1] + ab.B20 * pik[2];
+            rg[1] += ab.B01 * pik[0] + ab.B11 * pik[1] + ab.B21 * pik[2];
+            rg[2] += pik[0];
+            rg[3] += pik[1];
+            rg[4] += ab.a * pik[0] + ab.b * pik[1] + pik[2];
+            n.g = amax(n.g, rg[0]); n.g = amax(n.g, rg[1]);
+            if (k > 0) { n.g = amax(n.g, rg[2]); n.g = amax(n.g, rg[3]); n.g = amax(n.g, rg[4]); }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) st(R_RG, k, q, rg[q]);
+            // --- Riccati step (factorisation + affine right-hand side) ---
+            st_P(k, P);
+            const double w0 = P.p00 * rb0 + P.p10 * rb1 + P.p20 * rb2 + p0;
+            const double w1 = P.p10 * rb0 + P.p11 * rb1 + P.p21 * rb2 + p1;
+            const double w2 = P.p20 * rb0 + P.p21 * rb1 + P.p22 * rb2 + p2;
+            const double hu0 = rg[0] + gam[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
+            const double hu1 = rg[1] + gam[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
+            Gain g;
+            gain(P, ab, Gam[0], Gam[1], k > 0, g);
             double f0, f1;
-            solve2(id0, l10, id1, hu0, hu1, f0, f1);  // kff = -Huu^-1 hu
-            st(m.KFF, 2 * k + 0, f0); st(m.KFF, 2 * k + 1, f1);
+            solve2(g.id0, g.l10, g.id1, hu0, hu1, f0, f1);
+            st(R_KFF, k, 0, f0); st(R_KFF, k, 1, f1);
             if (k > 0) {
-                // hx = res_g_x + gamma_x + A^T w ; p_k = hx + K^T hu
-                const double hx0 = ld(m.RG, 5 * k + 2) + gam[2] + w0;
-                const double hx1 = ld(m.RG, 5 * k + 3) + gam[3] + w1;
-                const double hx2 = ld(m.RG, 5 * k + 4) + (a * w0 + b * w1 + w2);
-                p0 = hx0 + (K00 * hu0 + K10 * hu1);
-                p1 = hx1 + (K01 * hu0 + K11 * hu1);
-                p2 = hx2 + (K02 * hu0 + K12 * hu1);
+                const double a = ab.a, b = ab.b;
+                const double S02 = P.p00 * a + P.p10 * b + P.p20;
+                const double S12 = P.p10 * a + P.p11 * b + P.p21;
+                const double S22 = P.p20 * a + P.p21 * b + P.p22;
+                const double Hxx00 = (c.wg[2] + c.reg_prim) + Gam[2] + P.p00;
+                const double Hxx10 = P.p10;
+                const double Hxx11 = (c.wg[3] + c.reg_prim) + Gam[3] + P.p11;
+                const double Hxx20 = a * P.p00 + b * P.p10 + P.p20;
+                const double Hxx21 = a * P.p10 + b * P.p11 + P.p21;
+                const double Hxx22 = (c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22);
+                Sym3 Q;
+                Q.p00 = Hxx00 + (g.M00 * g.K00 + g.M10 * g.K10);
+                Q.p10 = Hxx10 + (g.M01 * g.K00 + g.M11 * g.K10);
+                Q.p11 = Hxx11 + (g.M01 * g.K01 + g.M11 * g.K11);
+                Q.p20 = Hxx20 + (g.X02 * g.K00 + g.X12 * g.K10);
+                Q.p21 = Hxx21 + (g.X02 * g.K01 + g.X12 * g.K11);
+                Q.p22 = Hxx22 + (g.X02 * g.K02 + g.X12 * g.K12);
+                const double hx0 = rg[2] + gam[2] + w0;
+                const double hx1 = rg[3] + gam[3] + w1;
+                const double hx2 = rg[4] + (a * w0 + b * w1 + w2);
+                p0 = hx0 + (g.K00 * hu0 + g.K10 * hu1);
+                p1 = hx1 + (g.K01 * hu0 + g.K11 * hu1);
+                p2 = hx2 + (g.K02 * hu0 + g.K12 * hu1);
+                P = Q;
             }
+            zxn[0] = z[2]; zxn[1] = z[3]; zxn[2] = z[4];
+            pik[0] = pim[0]; pik[1] = pim[1]; pik[2] = pim[2];
+            if (k > 0) cur = nxt;
         }
     }
-    // x = -(L D L^T)^-1 r for the 2x2 block
-    MPC_HD static void solve2(double id0, double l10, double id1, double r0, double r1, double& x0, double& x1) {
-        const double y1 = r1 - l10 * r0;
-        x1 = -(y1 * id1);
-        x0 = -(r0 * id0) - l10 * x1;
-    }
 
-    // ---- forward sweep.  Computes the primal step of all stages, the step lengths
-    //      (COMPUTE_ALPHA_QP) and the three sums that give mu_aff for any alpha.
-    //      mode 0: affine step -> DZA; mode 1/2: final step -> DZ, DPI and the stationarity
-    //      residual of the linear system (what HPIPM's refinement loop tests).
-    struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
-    MPC_HD void forward(int mode, double sigma_mu, FwdOut& o) const {
-        const int N = c.N;
-        double a_prim = -1.0, a_dual = -1.0, s1 = 0.0, s2 = 0.0, lin_g = 0.0;
-        double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0;  // stage-0 state is fixed
-        double dpm0 = 0.0, dpm1 = 0.0, dpm2 = 0.0;  // dpi_{k-1}
-        double* DZo = (mode == 0) ? m.DZA : m.DZ;
-        for (int k = 0; k < N; ++k) {
-            const double a = ld(m.AB, 8 * k), b = ld(m.AB, 8 * k + 1);
-            const double B00 = ld(m.AB, 8 * k + 2), B10 = ld(m.AB, 8 * k + 3), B20 = ld(m.AB, 8 * k + 4);
-            const double B01 = ld(m.AB, 8 * k + 5), B11 = ld(m.AB, 8 * k + 6), B21 = ld(m.AB, 8 * k + 7);
-            double du0 = ld(m.KFF, 2 * k), du1 = ld(m.KFF, 2 * k + 1);
-            if (k > 0) {
-                du0 += ld(m.K, 6 * k + 0) * dx0 + ld(m.K, 6 * k + 1) * dx1 + ld(m.K, 6 * k + 2) * dx2;
-                du1 += ld(m.K, 6 * k + 3) * dx0 + ld(m.K, 6 * k + 4) * dx1 + ld(m.K, 6 * k + 5) * dx2;
-            }
-            const double dz[5] = {du0, du1, dx0, dx1, dx2};
+    // ---- backward sweep with a new right-hand side (OCP_QP_SOLVE_KKT_STEP, backward half):
+    //      corrected complementarity -> gamma -> kff, p.  mode 1 / 2 as in con_correct.
+    struct BwIn {
+        Sym3 P;
+        AB8 ab;
+        double rg[5], rb[3], z[4], dza[4];
+        Bnd bn;
+    };
+    MPC_HD void ld_bw(int k, BwIn& r) const {
+        r.P = ld_P(k);
+        r.ab = ld_ab(k);
 #pragma unroll
-            for (int q = 0; q < 5; ++q) st(DZo, 5 * k + q, dz[q]);
-            // constraints: dt, dlam, step lengths, mu_aff sums
+        for (int q = 0; q < 5; ++q) r.rg[q] = ld(R_RG, k, q);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.rb[q] = ld(R_RB, k, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { r.z[q] = ld(R_Z, k, q); r.dza[q] = ld(R_DZA, k, q); }
+        r.bn = ld_bnd(k);
+    }
+    MPC_SWEEP void sweep_bw(int mode, double sigma_mu) const {
+        const int N = c.N;
+        double p0 = ld(R_RG, N, 2), p1 = ld(R_RG, N, 3), p2 = ld(R_RG, N, 4);
+        BwIn cur, nxt;
+        ld_bw(N - 1, cur);
+        for (int k = N - 1; k >= 0; --k) {
+            if (k > 0) ld_bw(k - 1, nxt);
             const int nb = (k == 0) ? 2 : 4;
-            double dlam_net[4] = {0, 0, 0, 0};
+            const AB8& ab = cur.ab;
+            const Sym3& P = cur.P;
+            st(R_PV, k, 0, p0); st(R_PV, k, 1, p1); st(R_PV, k, 2, p2);
+            const double w0 = P.p00 * cur.rb[0] + P.p10 * cur.rb[1] + P.p20 * cur.rb[2] + p0;
+            const double w1 = P.p10 * cur.rb[0] + P.p11 * cur.rb[1] + P.p21 * cur.rb[2] + p1;
+            const double w2 = P.p20 * cur.rb[0] + P.p21 * cur.rb[1] + P.p22 * cur.rb[2] + p2;
+            double Gam[4] = {0, 0, 0, 0}, gam[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < nb) {
                     Con q;
-                    con_load(k, j, ld(m.Z, 5 * k + j), q);
-                    if (mode != 0) con_correct(q, mode, ld(m.DZA, 5 * k + j), sigma_mu);
+                    con_make(j, cur.bn.lam[j], cur.bn.lam[4 + j], cur.bn.t[j], cur.bn.t[4 + j], cur.z[j], q);
+                    Gam[j] = con_Gamma(q);
+                    con_correct(q, mode, cur.dza[j], sigma_mu);
+                    gam[j] = con_gamma(q);
+                }
+            }
+            const double hu0 = cur.rg[0] + gam[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
+            const double hu1 = cur.rg[1] + gam[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
+            Gain g;
+            gain(P, ab, Gam[0], Gam[1], k > 0, g);
+            double f0, f1;
+            solve2(g.id0, g.l10, g.id1, hu0, hu1, f0, f1);
+            st(R_KFF, k, 0, f0); st(R_KFF, k, 1, f1);
+            if (k > 0) {
+                const double hx0 = cur.rg[2] + gam[2] + w0;
+                const double hx1 = cur.rg[3] + gam[3] + w1;
+                const double hx2 = cur.rg[4] + (ab.a * w0 + ab.b * w1 + w2);
+                p0 = hx0 + (g.K00 * hu0 + g.K10 * hu1);
+                p1 = hx1 + (g.K01 * hu0 + g.K11 * hu1);
+                p2 = hx2 + (g.K02 * hu0 + g.K12 * hu1);
+            }
+            if (k > 0) cur = nxt;
+        }
+    }
+
+    // ---- forward sweep: primal step of all stages, step lengths (COMPUTE_ALPHA_QP) and the
+    //      three sums that give mu_aff for any alpha.  FINAL = false: affine step -> DZA;
+    //      FINAL = true: final step -> DZ, DPI and the stationarity residual of the linear
+    //      system (what HPIPM's refinement loop and lq_fact = 1 switch test).
+    struct FwIn {
+        Sym3 P;
+        AB8 ab;
+        double kff[2], rb[3], z[4], dza[4], pv[3], rg[5];
+        Bnd bn;
+    };
+    template <bool FINAL>
+    MPC_HD void ld_fw(int k, FwIn& r) const {
+        r.P = ld_P(k);
+        r.ab = ld_ab(k);
+        r.kff[0] = ld(R_KFF, k, 0); r.kff[1] = ld(R_KFF, k, 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.rb[q] = ld(R_RB, k, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.z[q] = ld(R_Z, k, q);
+        r.bn = ld_bnd(k);
+        if (FINAL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r.dza[q] = ld(R_DZA, k, q);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r.pv[q] = ld(R_PV, k, q);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r.rg[q] = ld(R_RG, k, q);
+        }
+    }
+    struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
+    template <bool FINAL>
+    MPC_SWEEP void sweep_fw(int mode, double sigma_mu, FwdOut& o) const {
+        const int N = c.N;
+        double a_prim = -1.0, a_dual = -1.0, s1 = 0.0, s2 = 0.0, lin_g = 0.0;
+        double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0;     // stage-0 state is fixed
+        double dpm0 = 0.0, dpm1 = 0.0, dpm2 = 0.0;  // dpi_{k-1}
+        const int DZo = FINAL ? R_DZ : R_DZA;
+        FwIn cur, nxt;
+        ld_fw<FINAL>(0, cur);
+        for (int k = 0; k < N; ++k) {
+            if (k + 1 < N) ld_fw<FINAL>(k + 1, nxt);
+            const int nb = (k == 0) ? 2 : 4;
+            const AB8& ab = cur.ab;
+            Con q[4];
+            double Gam0 = 0.0, Gam1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nb) {
+                    con_make(j, cur.bn.lam[j], cur.bn.lam[4 + j], cur.bn.t[j], cur.bn.t[4 + j], cur.z[j], q[j]);
+                    if (j == 0) Gam0 = con_Gamma(q[j]);
+                    if (j == 1) Gam1 = con_Gamma(q[j]);
+                    if (FINAL) con_correct(q[j], mode, cur.dza[j], sigma_mu);
+                }
+            }
+            double du0 = cur.kff[0], du1 = cur.kff[1];
+            if (k > 0) {
+                Gain g;
+                gain(cur.P, ab, Gam0, Gam1, true, g);
+                du0 += g.K00 * dx0 + g.K01 * dx1 + g.K02 * dx2;
+                du1 += g.K10 * dx0 + g.K11 * dx1 + g.K12 * dx2;
+            }
+            const double dz[5] = {du0, du1, dx0, dx1, dx2};
+            if (FINAL) {
+#pragma unroll
+                for (int qq = 0; qq < 5; ++qq) st(DZo, k, qq, dz[qq]);
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) st(DZo, k, qq, dz[qq]);
+            }
+            double dlam_net[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nb) {
                     Step s;
-                    con_step(q, dz[j], s);
-                    if (a_dual * s.dl_l > q.lam_l) a_dual = q.lam_l / s.dl_l;
-                    if (a_prim * s.dt_l > q.t_l) a_prim = q.t_l / s.dt_l;
-                    if (a_dual * s.dl_u > q.lam_u) a_dual = q.lam_u / s.dl_u;
-                    if (a_prim * s.dt_u > q.t_u) a_prim = q.t_u / s.dt_u;
-                    s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
-                    s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
+                    con_step(q[j], dz[j], s);
+                    if (a_dual * s.dl_l > q[j].lam_l) a_dual = q[j].lam_l / s.dl_l;
+                    if (a_prim * s.dt_l > q[j].t_l) a_prim = q[j].t_l / s.dt_l;
+                    if (a_dual * s.dl_u > q[j].lam_u) a_dual = q[j].lam_u / s.dl_u;
+                    if (a_prim * s.dt_u > q[j].t_u) a_prim = q[j].t_u / s.dt_u;
+                    s1 += q[j].lam_l * s.dt_l + q[j].t_l * s.dl_l;
+                    s1 += q[j].lam_u * s.dt_u + q[j].t_u * s.dl_u;
                     s2 += s.dl_l * s.dt_l;
                     s2 += s.dl_u * s.dt_u;
                     dlam_net[j] = s.dl_u - s.dl_l;
                 }
             }
-            // dx+ = A dx + B du + rb
-            const double nx0 = ld(m.RB, 3 * k + 0) + (B00 * du0 + B01 * du1 + (dx0 + a * dx2));
-            const double nx1 = ld(m.RB, 3 * k + 1) + (B10 * du0 + B11 * du1 + (dx1 + b * dx2));
-            const double nx2 = ld(m.RB, 3 * k + 2) + (B20 * du0 + B21 * du1 + dx2);
-            if (mode != 0) {
-                // dpi_k = P_{k+1} dx+ + p_{k+1}
-                const double P00 = ld(m.P, 6 * k + 0), P10 = ld(m.P, 6 * k + 1), P11 = ld(m.P, 6 * k + 2);
-                const double P20 = ld(m.P, 6 * k + 3), P21 = ld(m.P, 6 * k + 4), P22 = ld(m.P, 6 * k + 5);
-                const double dp0 = P00 * nx0 + P10 * nx1 + P20 * nx2 + ld(m.PV, 3 * k + 0);
-                const double dp1 = P10 * nx0 + P11 * nx1 + P21 * nx2 + ld(m.PV, 3 * k + 1);
-                const double dp2 = P20 * nx0 + P21 * nx1 + P22 * nx2 + ld(m.PV, 3 * k + 2);
-                st(m.DPI, 3 * k + 0, dp0); st(m.DPI, 3 * k + 1, dp1); st(m.DPI, 3 * k + 2, dp2);
-                // stationarity rows of the linear system at this stage
-                const double lg0 = c.wg[0] * du0 + ld(m.RG, 5 * k + 0) + dlam_net[0] + (B00 * dp0 + B10 * dp1 + B20 * dp2);
-                const double lg1 = c.wg[1] * du1 + ld(m.RG, 5 * k + 1) + dlam_net[1] + (B01 * dp0 + B11 * dp1 + B21 * dp2);
+            const double nx0 = cur.rb[0] + (ab.B00 * du0 + ab.B01 * du1 + (dx0 + ab.a * dx2));
+            const double nx1 = cur.rb[1] + (ab.B10 * du0 + ab.B11 * du1 + (dx1 + ab.b * dx2));
+            const double nx2 = cur.rb[2] + (ab.B20 * du0 + ab.B21 * du1 + dx2);
+            if (FINAL) {
+                const Sym3& P = cur.P;
+                const double dp0 = P.p00 * nx0 + P.p10 * nx1 + P.p20 * nx2 + cur.pv[0];
+                const double dp1 = P.p10 * nx0 + P.p11 * nx1 + P.p21 * nx2 + cur.pv[1];
+                const double dp2 = P.p20 * nx0 + P.p21 * nx1 + P.p22 * nx2 + cur.pv[2];
+                st(R_DPI, k, 0, dp0); st(R_DPI, k, 1, dp1); st(R_DPI, k, 2, dp2);
+                const double lg0 = c.wg[0] * du0 + cur.rg[0] + dlam_net[0] + (ab.B00 * dp0 + ab.B10 * dp1 + ab.B20 * dp2);
+                const double lg1 = c.wg[1] * du1 + cur.rg[1] + dlam_net[1] + (ab.B01 * dp0 + ab.B11 * dp1 + ab.B21 * dp2);
                 lin_g = amax(lin_g, lg0); lin_g = amax(lin_g, lg1);
                 if (k > 0) {
-                    const double lg2 = c.wg[2] * dx0 + ld(m.RG, 5 * k + 2) + dlam_net[2] - dpm0 + dp0;
-                    const double lg3 = c.wg[3] * dx1 + ld(m.RG, 5 * k + 3) + dlam_net[3] - dpm1 + dp1;
-                    const double lg4 = c.wg[4] * dx2 + ld(m.RG, 5 * k + 4) - dpm2 + (a * dp0 + b * dp1 + dp2);
+                    const double lg2 = c.wg[2] * dx0 + cur.rg[2] + dlam_net[2] - dpm0 + dp0;
+                    const double lg3 = c.wg[3] * dx1 + cur.rg[3] + dlam_net[3] - dpm1 + dp1;
+                    const double lg4 = c.wg[4] * dx2 + cur.rg[4] - dpm2 + (ab.a * dp0 + ab.b * dp1 + dp2);
                     lin_g = amax(lin_g, lg2); lin_g = amax(lin_g, lg3); lin_g = amax(lin_g, lg4);
                 }
                 dpm0 = dp0; dpm1 = dp1; dpm2 = dp2;
             }
             dx0 = nx0; dx1 = nx1; dx2 = nx2;
+            if (k + 1 < N) cur = nxt;
         }
-        st(DZo, 5 * N + 0, 0.0); st(DZo, 5 * N + 1, 0.0);
-        st(DZo, 5 * N + 2, dx0); st(DZo, 5 * N + 3, dx1); st(DZo, 5 * N + 4, dx2);
-        if (mode != 0) {
-            const double lg2 = c.we[0] * dx0 + ld(m.RG, 5 * N + 2) - dpm0;
-            const double lg3 = c.we[1] * dx1 + ld(m.RG, 5 * N + 3) - dpm1;
-            const double lg4 = c.we[2] * dx2 + ld(m.RG, 5 * N + 4) - dpm2;
+        if (FINAL) {
+            st(DZo, N, 2, dx0); st(DZo, N, 3, dx1); st(DZo, N, 4, dx2);
+            const double lg2 = c.we[0] * dx0 + ld(R_RG, N, 2) - dpm0;
+            const double lg3 = c.we[1] * dx1 + ld(R_RG, N, 3) - dpm1;
+            const double lg4 = c.we[2] * dx2 + ld(R_RG, N, 4) - dpm2;
             lin_g = amax(lin_g, lg2); lin_g = amax(lin_g, lg3); lin_g = amax(lin_g, lg4);
         }
         o.a_prim = -a_prim; o.a_dual = -a_dual; o.s1 = s1; o.s2 = s2; o.lin_g = lin_g;
     }
 
-    // ---- UPDATE_VAR_QP fused with the next residual evaluation (OCP_QP_RES_COMPUTE) ----
-    MPC_HD void update_and_residual(int mode, double sigma_mu, double alpha, Norms& n) const {
-        const int N = c.N;
-        n.g = n.b = n.d = n.m = n.musum = 0.0;
-        double pim[3] = {0.0, 0.0, 0.0};
-        double z[5];
-        update_stage_primal(0, mode, sigma_mu, alpha, z);
-        for (int k = 0; k <= N; ++k) {
-            double zn[5] = {0, 0, 0, 0, 0}, pik[3] = {0, 0, 0};
-            if (k < N) {
-                update_stage_primal(k + 1, mode, sigma_mu, alpha, zn);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    pik[q] = ld(m.PIQ, 3 * k + q) + alpha * ld(m.DPI, 3 * k + q);
-                    st(m.PIQ, 3 * k + q, pik[q]);
-                }
-            }
-            residual_stage(k, z, zn + 2, pim, pik, n);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) z[q] = zn[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pim[q] = pik[q];
-        }
-    }
-    // zeta, lam, t of stage k += alpha * step (dlam, dt recomputed exactly as in forward())
-    MPC_HD void update_stage_primal(int k, int mode, double sigma_mu, double alpha, double z[5]) const {
-        const int N = c.N;
-        double zo[5], dz[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { zo[q] = ld(m.Z, 5 * k + q); dz[q] = ld(m.DZ, 5 * k + q); }
-        if (k < N) {
-            const int nb = (k == 0) ? 2 : 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < nb) {
-                    Con q;
-                    con_load(k, j, zo[j], q);
-                    con_correct(q, mode, ld(m.DZA, 5 * k + j), sigma_mu);
-                    Step s;
-                    con_step(q, dz[j], s);
-                    double ll = q.lam_l + alpha * s.dl_l, lu = q.lam_u + alpha * s.dl_u;
-                    double tl = q.t_l + alpha * s.dt_l, tu = q.t_u + alpha * s.dt_u;
-                    if (ll < c.lam_min) ll = c.lam_min;
-                    if (lu < c.lam_min) lu = c.lam_min;
-                    if (tl < c.t_min) tl = c.t_min;
-                    if (tu < c.t_min) tu = c.t_min;
-                    st(m.LAM, 8 * k + j, ll); st(m.LAM, 8 * k + 4 + j, lu);
-                    st(m.T, 8 * k + j, tl);   st(m.T, 8 * k + 4 + j, tu);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            z[q] = zo[q] + alpha * dz[q];
-            st(m.Z, 5 * k + q, z[q]);
-        }
-    }
-
     // ---- the whole RTI step of this lane ----
     MPC_HD void rti_step() const {
         const int N = c.N;
-        for (int k = 0; k < N; ++k) linearize_stage(k);
-
+        prepare();
         Norms n;
-        init_and_residual(n);
+        sweep_bu<true>(0, 0.0, 0.0, n);
         const int nc = 4 + 8 * (N - 1);
         const double nc_inv = 1.0 / nc;
         double mu = n.musum * nc_inv;
@@ -564,36 +723,34 @@ struct Lane {
         while (kk < c.iter_max && alpha > c.alpha_min &&
                (n.g > c.res_g_max || n.b > c.res_b_max || n.d > c.res_d_max ||
                 fabs(n.m - c.tau_min) > c.res_m_max)) {
-            // --- OCP_QP_IPM_DELTA_STEP ---
-            backward(0, 0.0);
+            // --- OCP_QP_IPM_DELTA_STEP (the factorisation was done by the last BU sweep) ---
             FwdOut fa;
-            forward(0, 0.0, fa);
-            double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;  // -max(-ap,-ad)
-            // mu_aff = sum (lam + a dlam)(t + a dt) / nc
+            sweep_fw<false>(0, 0.0, fa);
+            const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
             const double mu_aff0 = (n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nc_inv;
             const double tmp = mu_aff0 / mu;
             const double sigma = tmp * tmp * tmp;
             double sigma_mu = sigma * mu;
             if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
             int mode = 1;
-            backward(1, sigma_mu);
+            sweep_bw(1, sigma_mu);
             FwdOut fc;
-            forward(1, sigma_mu, fc);
+            sweep_fw<true>(1, sigma_mu, fc);
             alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
             // conditional predictor-corrector: fall back to pure centering
             const double mu_aff1 = (n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nc_inv;
             if (mu_aff1 > 2.0 * mu_aff0) {
                 mode = 2;
-                backward(2, sigma_mu);
-                forward(2, sigma_mu, fc);
+                sweep_bw(2, sigma_mu);
+                sweep_fw<true>(2, sigma_mu, fc);
                 alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
             }
             if (!(fc.lin_g < c.itref_tol_g)) diag |= MPC_DIAG_ITREF;
             if (!(fc.lin_g < c.lq_tol)) diag |= MPC_DIAG_LQ;
-            // --- UPDATE_VAR_QP + OCP_QP_RES_COMPUTE ---
+            // --- UPDATE_VAR_QP + OCP_QP_RES_COMPUTE (+ next factorisation) ---
             double a_upd = alpha;
             if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
-            update_and_residual(mode, sigma_mu, a_upd, n);
+            sweep_bu<false>(mode, sigma_mu, a_upd, n);
             mu = n.musum * nc_inv;
             ++kk;
         }
@@ -604,22 +761,22 @@ struct Lane {
         else if (mu != mu) hs = 3;
         else hs = 0;
         const bool ok = (hs == 0 || hs == 1);
-        m.QPITER[i] = kk;
-        m.DIAG[i] = diag;
-        m.STATUS[i] = ok ? 0 : 4;
+        m.QPITER[wbase + lane] = kk;
+        m.DIAG[wbase + lane] = diag;
+        m.STATUS[wbase + lane] = ok ? 0 : 4;
         if (ok) {
             for (int k = 0; k <= N; ++k) {
                 if (k < N) {
-                    st(m.U, 2 * k, ld(m.Z, 5 * k)); st(m.U, 2 * k + 1, ld(m.Z, 5 * k + 1));
-                    st(m.PI, 3 * k, ld(m.PIQ, 3 * k)); st(m.PI, 3 * k + 1, ld(m.PIQ, 3 * k + 1));
-                    st(m.PI, 3 * k + 2, ld(m.PIQ, 3 * k + 2));
+                    st(R_U, k, 0, ld(R_Z, k, 0)); st(R_U, k, 1, ld(R_Z, k, 1));
+                    st(R_PI, k, 0, ld(R_PIQ, k, 0)); st(R_PI, k, 1, ld(R_PIQ, k, 1));
+                    st(R_PI, k, 2, ld(R_PIQ, k, 2));
                 }
-                st(m.X, 3 * k, ld(m.Z, 5 * k + 2)); st(m.X, 3 * k + 1, ld(m.Z, 5 * k + 3));
-                st(m.X, 3 * k + 2, ld(m.Z, 5 * k + 4));
+                st(R_X, k, 0, ld(R_Z, k, 2)); st(R_X, k, 1, ld(R_Z, k, 3));
+                st(R_X, k, 2, ld(R_Z, k, 4));
             }
         }
-        st(m.U0, 0, ld(m.U, 0));
-        st(m.U0, 1, ld(m.U, 1));
+        st(R_U0, c.N, 0, ld(R_U, 0, 0));
+        st(R_U0, c.N, 1, ld(R_U, 0, 1));
     }
 };
 
