@@ -24,6 +24,8 @@
 #include <math.h>
 #include <stddef.h>
 
+#include <type_traits>
+
 #if defined(__HIPCC__)
 #define MPC_HD __host__ __device__ __forceinline__
 #define MPC_SWEEP __host__ __device__ __forceinline__
@@ -105,12 +107,16 @@ struct Lane {
         voff = lane_ * 8u;
     }
     __device__ __forceinline__ double ld(int field, int k, int comp) const {
-        const unsigned so = (unsigned)(k * MPC_RPS + field + comp) << 9;
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, so, 0));
+        // rows are split 8 + 3 bits: the low part folds into the instruction's 12-bit immediate
+        // offset, so one scalar offset serves 8 rows
+        const int row = field + comp;
+        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + ((unsigned)(row & 7) << 9), so, 0));
     }
     __device__ __forceinline__ void st(int field, int k, int comp, double v) const {
-        const unsigned so = (unsigned)(k * MPC_RPS + field + comp) << 9;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, voff, so, 0);
+        const int row = field + comp;
+        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, voff + ((unsigned)(row & 7) << 9), so, 0);
     }
 #else
     double* blk;
@@ -266,7 +272,7 @@ struct Lane {
     }
 
     struct Norms { double g, b, d, m, musum; };
-    MPC_HD static double amax(double cur, double v) { const double a = fabs(v); return a > cur ? a : cur; }
+    MPC_HD static double amax(double cur, double v) { return fmax(cur, fabs(v)); }
 
     // x = -(L D L^T)^-1 r for the 2x2 block
     MPC_HD static void solve2(double id0, double l10, double id1, double r0, double r1, double& x0, double& x1) {
@@ -329,7 +335,7 @@ struct Lane {
                             else { tl = c.thr0; z[j] = c.lb[j] + c.thr0; }
                         } else if (tu < c.thr0) { tu = c.thr0; z[j] = c.ub[j] - c.thr0; }
                         st(R_T, k, j, tl); st(R_T, k, 4 + j, tu);
-                        st(R_LAM, k, j, c.mu0 / tl); st(R_LAM, k, 4 + j, c.mu0 / tu);
+                        st(R_LAM, k, j, c.mu0 * rcp(tl)); st(R_LAM, k, 4 + j, c.mu0 * rcp(tu));
                     } else {  // stage 0 has no state bounds: benign values keep the unused lanes finite
                         st(R_T, k, j, 1.0); st(R_T, k, 4 + j, 1.0);
                         st(R_LAM, k, j, 0.0); st(R_LAM, k, 4 + j, 0.0);
@@ -409,9 +415,11 @@ struct Lane {
 
         BuIn cur, nxt;
         ld_bu<FIRST>(N - 1, cur);
-        for (int k = N - 1; k >= 0; --k) {
-            if (k > 0) ld_bu<FIRST>(k - 1, nxt);  // software prefetch of the next stage
-            const int nb = (k == 0) ? 2 : 4;
+        // stage 0 (no state variables, 2 bounds) is peeled off at compile time
+        auto body = [&](auto s0tag, const int k) {
+            constexpr bool S0 = decltype(s0tag)::value;
+            constexpr int nb = S0 ? 2 : 4;
+            if (!S0) ld_bu<FIRST>(k - 1, nxt);  // software prefetch of the next stage
             const AB8& ab = cur.ab;
             // --- apply the previous step to this stage ---
             double z[5];
@@ -445,7 +453,7 @@ struct Lane {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 pim[q] = FIRST ? cur.pim[q] : cur.pim[q] + alpha * cur.dpim[q];
-                if (!FIRST && k > 0) st(R_PIQ, k - 1, q, pim[q]);
+                if (!FIRST && !S0) st(R_PIQ, k - 1, q, pim[q]);
             }
             // --- residuals of this stage at the new point ---
             double rg[5];
@@ -480,7 +488,7 @@ struct Lane {
             rg[3] += pik[1];
             rg[4] += ab.a * pik[0] + ab.b * pik[1] + pik[2];
             n.g = amax(n.g, rg[0]); n.g = amax(n.g, rg[1]);
-            if (k > 0) { n.g = amax(n.g, rg[2]); n.g = amax(n.g, rg[3]); n.g = amax(n.g, rg[4]); }
+            if (!S0) { n.g = amax(n.g, rg[2]); n.g = amax(n.g, rg[3]); n.g = amax(n.g, rg[4]); }
 #pragma unroll
             for (int q = 0; q < 5; ++q) st(R_RG, k, q, rg[q]);
             // --- Riccati step (factorisation + affine right-hand side) ---
@@ -491,11 +499,11 @@ struct Lane {
             const double hu0 = rg[0] + gam[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
             const double hu1 = rg[1] + gam[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
             Gain g;
-            gain(P, ab, Gam[0], Gam[1], k > 0, g);
+            gain(P, ab, Gam[0], Gam[1], !S0, g);
             double f0, f1;
             solve2(g.id0, g.l10, g.id1, hu0, hu1, f0, f1);
             st(R_KFF, k, 0, f0); st(R_KFF, k, 1, f1);
-            if (k > 0) {
+            if (!S0) {
                 const double a = ab.a, b = ab.b;
                 const double S02 = P.p00 * a + P.p10 * b + P.p20;
                 const double S12 = P.p10 * a + P.p11 * b + P.p21;
@@ -523,8 +531,10 @@ struct Lane {
             }
             zxn[0] = z[2]; zxn[1] = z[3]; zxn[2] = z[4];
             pik[0] = pim[0]; pik[1] = pim[1]; pik[2] = pim[2];
-            if (k > 0) cur = nxt;
-        }
+            if (!S0) cur = nxt;
+        };
+        for (int k = N - 1; k >= 1; --k) body(std::false_type{}, k);
+        body(std::true_type{}, 0);
     }
 
     // ---- backward sweep with a new right-hand side (OCP_QP_SOLVE_KKT_STEP, backward half):
@@ -551,9 +561,10 @@ struct Lane {
         double p0 = ld(R_RG, N, 2), p1 = ld(R_RG, N, 3), p2 = ld(R_RG, N, 4);
         BwIn cur, nxt;
         ld_bw(N - 1, cur);
-        for (int k = N - 1; k >= 0; --k) {
-            if (k > 0) ld_bw(k - 1, nxt);
-            const int nb = (k == 0) ? 2 : 4;
+        auto body = [&](auto s0tag, const int k) {
+            constexpr bool S0 = decltype(s0tag)::value;
+            constexpr int nb = S0 ? 2 : 4;
+            if (!S0) ld_bw(k - 1, nxt);
             const AB8& ab = cur.ab;
             const Sym3& P = cur.P;
             st(R_PV, k, 0, p0); st(R_PV, k, 1, p1); st(R_PV, k, 2, p2);
@@ -574,11 +585,11 @@ struct Lane {
             const double hu0 = cur.rg[0] + gam[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
             const double hu1 = cur.rg[1] + gam[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
             Gain g;
-            gain(P, ab, Gam[0], Gam[1], k > 0, g);
+            gain(P, ab, Gam[0], Gam[1], !S0, g);
             double f0, f1;
             solve2(g.id0, g.l10, g.id1, hu0, hu1, f0, f1);
             st(R_KFF, k, 0, f0); st(R_KFF, k, 1, f1);
-            if (k > 0) {
+            if (!S0) {
                 const double hx0 = cur.rg[2] + gam[2] + w0;
                 const double hx1 = cur.rg[3] + gam[3] + w1;
                 const double hx2 = cur.rg[4] + (ab.a * w0 + ab.b * w1 + w2);
@@ -586,8 +597,10 @@ struct Lane {
                 p1 = hx1 + (g.K01 * hu0 + g.K11 * hu1);
                 p2 = hx2 + (g.K02 * hu0 + g.K12 * hu1);
             }
-            if (k > 0) cur = nxt;
-        }
+            if (!S0) cur = nxt;
+        };
+        for (int k = N - 1; k >= 1; --k) body(std::false_type{}, k);
+        body(std::true_type{}, 0);
     }
 
     // ---- forward sweep: primal step of all stages, step lengths (COMPUTE_ALPHA_QP) and the
@@ -629,9 +642,10 @@ struct Lane {
         const int DZo = FINAL ? R_DZ : R_DZA;
         FwIn cur, nxt;
         ld_fw<FINAL>(0, cur);
-        for (int k = 0; k < N; ++k) {
+        auto body = [&](auto s0tag, const int k) {
+            constexpr bool S0 = decltype(s0tag)::value;
+            constexpr int nb = S0 ? 2 : 4;
             if (k + 1 < N) ld_fw<FINAL>(k + 1, nxt);
-            const int nb = (k == 0) ? 2 : 4;
             const AB8& ab = cur.ab;
             Con q[4];
             double Gam0 = 0.0, Gam1 = 0.0;
@@ -645,7 +659,7 @@ struct Lane {
                 }
             }
             double du0 = cur.kff[0], du1 = cur.kff[1];
-            if (k > 0) {
+            if (!S0) {
                 Gain g;
                 gain(cur.P, ab, Gam0, Gam1, true, g);
                 du0 += g.K00 * dx0 + g.K01 * dx1 + g.K02 * dx2;
@@ -665,10 +679,10 @@ struct Lane {
                 if (j < nb) {
                     Step s;
                     con_step(q[j], dz[j], s);
-                    if (a_dual * s.dl_l > q[j].lam_l) a_dual = q[j].lam_l / s.dl_l;
-                    if (a_prim * s.dt_l > q[j].t_l) a_prim = q[j].t_l / s.dt_l;
-                    if (a_dual * s.dl_u > q[j].lam_u) a_dual = q[j].lam_u / s.dl_u;
-                    if (a_prim * s.dt_u > q[j].t_u) a_prim = q[j].t_u / s.dt_u;
+                    if (a_dual * s.dl_l > q[j].lam_l) a_dual = q[j].lam_l * rcp(s.dl_l);
+                    if (a_prim * s.dt_l > q[j].t_l) a_prim = q[j].t_l * rcp(s.dt_l);
+                    if (a_dual * s.dl_u > q[j].lam_u) a_dual = q[j].lam_u * rcp(s.dl_u);
+                    if (a_prim * s.dt_u > q[j].t_u) a_prim = q[j].t_u * rcp(s.dt_u);
                     s1 += q[j].lam_l * s.dt_l + q[j].t_l * s.dl_l;
                     s1 += q[j].lam_u * s.dt_u + q[j].t_u * s.dl_u;
                     s2 += s.dl_l * s.dt_l;
@@ -688,7 +702,7 @@ struct Lane {
                 const double lg0 = c.wg[0] * du0 + cur.rg[0] + dlam_net[0] + (ab.B00 * dp0 + ab.B10 * dp1 + ab.B20 * dp2);
                 const double lg1 = c.wg[1] * du1 + cur.rg[1] + dlam_net[1] + (ab.B01 * dp0 + ab.B11 * dp1 + ab.B21 * dp2);
                 lin_g = amax(lin_g, lg0); lin_g = amax(lin_g, lg1);
-                if (k > 0) {
+                if (!S0) {
                     const double lg2 = c.wg[2] * dx0 + cur.rg[2] + dlam_net[2] - dpm0 + dp0;
                     const double lg3 = c.wg[3] * dx1 + cur.rg[3] + dlam_net[3] - dpm1 + dp1;
                     const double lg4 = c.wg[4] * dx2 + cur.rg[4] - dpm2 + (ab.a * dp0 + ab.b * dp1 + dp2);
@@ -698,7 +712,9 @@ struct Lane {
             }
             dx0 = nx0; dx1 = nx1; dx2 = nx2;
             if (k + 1 < N) cur = nxt;
-        }
+        };
+        body(std::true_type{}, 0);
+        for (int k = 1; k < N; ++k) body(std::false_type{}, k);
         if (FINAL) {
             st(DZo, N, 2, dx0); st(DZo, N, 3, dx1); st(DZo, N, 4, dx2);
             const double lg2 = c.we[0] * dx0 + ld(R_RG, N, 2) - dpm0;
