@@ -19,21 +19,80 @@
 using namespace mpc;
 
 #define MPC_WAVE 64
+#define MPC_MAX_PHASES 8
+// Phase schedule: batches up to this size run as one phase (latency path)
+#define MPC_SINGLE_PHASE_MAX 2048
 
 // ------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------
 
-// One SQP-RTI step per lane (H4/H15: replaces the serial loop of
+// One phase of the SQP-RTI step, one OCP per lane (H4/H15: replaces the serial loop of
 // mobile_robot_acados_batch_solve, acados_solver_mobile_robot.c:951-961).
-__global__ __launch_bounds__(MPC_WAVE) void k_rti(Consts c, Mem m, int B, int iters) {
+//
+// The HPIPM iteration count differs per instance (mean ~8, stragglers 20+), and a wave whose
+// lanes have mostly retired still pays the full latency of every sweep.  So the step runs in
+// phases: a wave leaves a phase as soon as fewer than `min_active` of its lanes (default 8
+// of 64) are still iterating (or all are done); finished lanes write their result to their HOME capsule, the
+// others park their scalars, k_compact packs the still-running instances densely into the
+// other workspace, and the next phase continues with full waves.  The last phase
+// (min_active = 0) runs every instance to completion.  No host synchronisation: the number of
+// live instances is read from device memory and surplus blocks exit at once.
+__global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home, const int* count_in, int B,
+                                                    int first, int min_active, int* flags) {
+    const int cnt = first ? B : *count_in;
     const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    if (wbase >= (size_t)cnt) return;  // wave-uniform
     const unsigned l = threadIdx.x;
-    if (wbase + l >= (size_t)B) return;
-    Lane lane(c, m, wbase, l);
-    for (int q = 0; q < iters; ++q) {
-        lane.rti_step();
-        if (m.STATUS[wbase + l] != 0) break;
+    const bool valid = wbase + l < (size_t)cnt;
+    Lane lane(c, cur, wbase, l);
+    Lane::State s;
+    s.kk = 0; s.diag = 0; s.alpha = 0.0; s.mu = 0.0; s.home = 0.0;
+    s.n.g = s.n.b = s.n.d = s.n.m = s.n.musum = 0.0;
+    if (valid) {
+        if (first) lane.begin(s, wbase + l);
+        else lane.load_state(s);
+    }
+    for (;;) {
+        const bool go = valid && lane.cont(s);
+        const int nact = __popcll(__ballot(go));
+        if (nact == 0 || nact < min_active) break;
+        if (go) lane.iterate(s);
+    }
+    const bool go = valid && lane.cont(s);
+    if (valid) {
+        if (go) lane.save_state(s);
+        else lane.finish(s, home);
+    }
+    if (flags && valid) flags[wbase + l] = go ? 1 : 0;
+}
+
+// Packs the instances that are still iterating (flags) densely into the other workspace.
+// Placement is by atomic ticket, so the order is not deterministic — results do not depend
+// on it (instances are independent and carry their home index).
+__global__ __launch_bounds__(MPC_WAVE) void k_compact(Mem src, Mem dst, const int* count_in, int B, int first,
+                                                      const int* flags, int* count_out, int N) {
+    const int cnt = first ? B : *count_in;
+    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    if (wbase >= (size_t)cnt) return;
+    const unsigned l = threadIdx.x;
+    const bool a = (wbase + l < (size_t)cnt) && flags[wbase + l] != 0;
+    const unsigned long long mask = __ballot(a);
+    const int n = __popcll(mask);
+    if (n == 0) return;
+    int base = 0;
+    if (l == (unsigned)(__ffsll((long long)mask) - 1)) base = atomicAdd(count_out, n);
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (!a) return;
+    const size_t d = (size_t)base + __popcll(mask & ((1ull << l) - 1ull));
+    const double* sc = reinterpret_cast<const double*>(src.slab + (wbase >> 6) * src.wave_bytes) + l;
+    double* dc = reinterpret_cast<double*>(dst.slab + (d >> 6) * dst.wave_bytes) + (d & 63);
+    for (int k = 0; k <= N; ++k) {
+        const size_t o = (size_t)(k * MPC_RPS) << 6;
+#pragma unroll 8
+        for (int r = MPC_CARRY_A0; r < MPC_CARRY_A1; ++r) dc[o + ((size_t)r << 6)] = sc[o + ((size_t)r << 6)];
+#pragma unroll 8
+        for (int r = MPC_CARRY_B0; r < MPC_CARRY_B1; ++r) dc[o + ((size_t)r << 6)] = sc[o + ((size_t)r << 6)];
     }
 }
 
@@ -132,9 +191,11 @@ struct Shard {
     size_t S = 0;      // padded stride
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    char* slab = nullptr;
+    char* slab = nullptr;    // primary workspace: capsules (home), inputs, phase 0
+    char* slab2 = nullptr;   // secondary workspace for compacted stragglers (lazily sized)
     int* islab = nullptr;
-    Mem mem;
+    int* phase_ints = nullptr;  // [MPC_MAX_PHASES] live counts, then [S] flags
+    Mem mem, mem2;
     // AoS staging for the host-pointer entry points
     double *s_x0 = nullptr, *s_yref = nullptr, *s_yrefe = nullptr, *s_u0 = nullptr;
     double *s_xt = nullptr, *s_ut = nullptr, *s_pi = nullptr;
@@ -163,7 +224,7 @@ static void free_shard(Shard& s) {
     if (s.device < 0) return;
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
-    (void)hipFree(s.slab); (void)hipFree(s.islab);
+    (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
@@ -188,7 +249,32 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
     const int iters = h->spec.sqp_max_iter > 1 ? h->spec.sqp_max_iter : 1;
-    hipLaunchKernelGGL(k_rti, dim3((n + MPC_WAVE - 1) / MPC_WAVE), dim3(MPC_WAVE), 0, st, h->consts, m, n, iters);
+    const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
+    for (int it = 0; it < iters; ++it) {
+        if (n <= MPC_SINGLE_PHASE_MAX || !s.slab2) {
+            hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, m, m, (const int*)nullptr, n, 1, 0, (int*)nullptr);
+        } else {
+            // phases 0..P-1; a wave hands over when fewer than MINACT of its lanes still iterate.
+            // Measured on MI355X (65536 x N=50): P=2, MINACT=8 is the optimum (20.4 ms/tick vs 25.0
+            // single-phase; more phases or an earlier hand-over cost more in compaction traffic
+            // than they save).  MPC_PHASES / MPC_MIN_ACTIVE override for experiments.
+            static const int P = getenv("MPC_PHASES") ? atoi(getenv("MPC_PHASES")) : 2;
+            static const int MINACT = getenv("MPC_MIN_ACTIVE") ? atoi(getenv("MPC_MIN_ACTIVE")) : MPC_WAVE / 8;
+            int* counts = s.phase_ints;
+            int* flags = s.phase_ints + MPC_MAX_PHASES;
+            HIPCHK(h, hipMemsetAsync(counts, 0, MPC_MAX_PHASES * sizeof(int), st));
+            for (int p = 0; p < P; ++p) {
+                const Mem& cur = (p % 2 == 0) ? m : s.mem2;
+                const Mem& oth = (p % 2 == 0) ? s.mem2 : m;
+                const bool last = (p == P - 1);
+                hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, cur, m, counts + p, n, p == 0 ? 1 : 0,
+                                   last ? 0 : MINACT, flags);
+                if (!last)
+                    hipLaunchKernelGGL(k_compact, wgrid, wblk, 0, st, cur, oth, counts + p, n, p == 0 ? 1 : 0, flags,
+                                       counts + p + 1, N);
+            }
+        }
+    }
     if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
     if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
@@ -275,6 +361,15 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
             HIPCHK(h, hipMemsetAsync(s.islab, 0, 3 * s.S * sizeof(int), s.stream));
             s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
+            if (capa > MPC_SINGLE_PHASE_MAX) {
+                // compaction only ever moves instances that are still iterating after a wave
+                // dropped below half occupancy, but size for the worst case
+                HIPCHK(h, hipMalloc(&s.slab2, nbytes));
+                HIPCHK(h, hipMemsetAsync(s.slab2, 0, nbytes, s.stream));
+                s.mem2 = make_mem(s.slab2, s.islab, (size_t)capa, N);
+            }
+            HIPCHK(h, hipMalloc(&s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int)));
+            HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), s.stream));
             HIPCHK(h, hipMalloc(&s.s_x0, sizeof(double) * 3 * capa));
             HIPCHK(h, hipMalloc(&s.s_yref, sizeof(double) * 5 * N * capa));
             HIPCHK(h, hipMalloc(&s.s_yrefe, sizeof(double) * 3 * capa));
@@ -461,6 +556,19 @@ double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
             h->last_ms = ms;
     }
     return h->last_ms;
+}
+// Development/diagnostic: live-instance counts at the start of phases 1..7 of the last solve
+// on the first shard (phase schedule of k_phase / k_compact).
+int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8) {
+    if (!h || !out8 || h->shards.empty()) return -1;
+    Shard& s = h->shards[0];
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    HIPCHK(h, hipSetDevice(s.device));
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    HIPCHK(h, hipMemcpy(out8, s.phase_ints, MPC_MAX_PHASES * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipSetDevice(prev);
+    return 0;
 }
 int mpc_batch_horizon(const mpc_batch_t* h) { return h ? h->spec.N : -1; }
 int mpc_batch_capacity(const mpc_batch_t* h) { return h ? h->capacity : -1; }

@@ -63,7 +63,7 @@ enum : int {
     R_U = 3,      // 2   capsule: controls u_k
     R_PI = 5,     // 3   capsule: multipliers of the dynamics
     R_YREF = 8,   // 5   input: y_ref of stage k          (stage N: y_ref_e in rows 0..2)
-    R_AB = 13,    // 8   a, b, B00, B10, B20, B01, B11, B21 (stage N: x0bar rows 0..2, u0 out rows 3..4)
+    R_AB = 13,    // 8   a, b, B00, B10, B20, B01, B11, B21 (stage N: x0bar in rows 0..2)
     R_C = 21,     // 3   affine term of the dynamics in absolute variables
     R_Z = 24,     // 5   zeta = z + dz  [v, delta, x, y, psi]
     R_PIQ = 29,   // 3   QP multipliers pi
@@ -71,14 +71,14 @@ enum : int {
     R_T = 40,     // 8   slacks t, same order
     R_P = 48,     // 6   value function P_{k+1} (sym: 00,10,11,20,21,22)
     R_KFF = 54,   // 2   feed-forward of the current right-hand side
-    R_PV = 56,    // 3   p_{k+1}
+    R_PV = 56,    // 3   p_{k+1}                              (stage N: u0 out in rows 0..1)
     R_RG = 59,    // 5   res_g
     R_RB = 64,    // 3   res_b
     R_DZA = 67,   // 4   affine step of the bounded variables
     R_DZ = 71,    // 5   final step
     R_DPI = 76,   // 3   final step of pi
     MPC_RPS = 80, // rows per stage
-    R_YREFE = R_YREF, R_X0 = R_AB, R_U0 = R_AB + 3
+    R_YREFE = R_YREF, R_X0 = R_AB, R_U0 = R_PV  // stage-N aliases (R_U0 must stay outside the carry ranges)
 };
 
 struct Mem {
@@ -215,6 +215,17 @@ struct Lane {
         return r;
     }
 
+    // Stage indices are the same in every lane, but after control-flow restructuring the
+    // compiler cannot always prove it and would wrap every buffer access in a waterfall loop;
+    // reading the value from the first active lane states the uniformity explicitly.
+    MPC_HD static int uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_readfirstlane(v);
+#else
+        return v;
+#endif
+    }
+
     // reciprocal: v_rcp_f64 + two Newton steps (what the compiler's own f64 division expands
     // to, minus the scaling/fix-up for subnormal and huge quotients that cannot occur here)
     MPC_HD static double rcp(double x) {
@@ -315,7 +326,7 @@ struct Lane {
 
     // ---- preparation sweep (forward): ERK4 linearisation + OCP_QP_INIT_VAR cold start ----
     MPC_SWEEP void prepare() const {
-        const int N = c.N;
+        const int N = uniform(c.N);
         for (int k = 0; k <= N; ++k) {
             if (k < N) linearize_stage(k);
             double z[5];
@@ -388,7 +399,7 @@ struct Lane {
 
     template <bool FIRST>
     MPC_SWEEP void sweep_bu(int mode, double sigma_mu, double alpha, Norms& n) const {
-        const int N = c.N;
+        const int N = uniform(c.N);
         n.g = n.b = n.d = n.m = n.musum = 0.0;
         // ---- terminal stage ----
         double zxn[3], pik[3];
@@ -416,7 +427,8 @@ struct Lane {
         BuIn cur, nxt;
         ld_bu<FIRST>(N - 1, cur);
         // stage 0 (no state variables, 2 bounds) is peeled off at compile time
-        auto body = [&](auto s0tag, const int k) {
+        auto body = [&](auto s0tag, const int k_) {
+            const int k = uniform(k_);
             constexpr bool S0 = decltype(s0tag)::value;
             constexpr int nb = S0 ? 2 : 4;
             if (!S0) ld_bu<FIRST>(k - 1, nxt);  // software prefetch of the next stage
@@ -557,11 +569,12 @@ struct Lane {
         r.bn = ld_bnd(k);
     }
     MPC_SWEEP void sweep_bw(int mode, double sigma_mu) const {
-        const int N = c.N;
+        const int N = uniform(c.N);
         double p0 = ld(R_RG, N, 2), p1 = ld(R_RG, N, 3), p2 = ld(R_RG, N, 4);
         BwIn cur, nxt;
         ld_bw(N - 1, cur);
-        auto body = [&](auto s0tag, const int k) {
+        auto body = [&](auto s0tag, const int k_) {
+            const int k = uniform(k_);
             constexpr bool S0 = decltype(s0tag)::value;
             constexpr int nb = S0 ? 2 : 4;
             if (!S0) ld_bw(k - 1, nxt);
@@ -635,14 +648,15 @@ struct Lane {
     struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
     template <bool FINAL>
     MPC_SWEEP void sweep_fw(int mode, double sigma_mu, FwdOut& o) const {
-        const int N = c.N;
+        const int N = uniform(c.N);
         double a_prim = -1.0, a_dual = -1.0, s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0;     // stage-0 state is fixed
         double dpm0 = 0.0, dpm1 = 0.0, dpm2 = 0.0;  // dpi_{k-1}
         const int DZo = FINAL ? R_DZ : R_DZA;
         FwIn cur, nxt;
         ld_fw<FINAL>(0, cur);
-        auto body = [&](auto s0tag, const int k) {
+        auto body = [&](auto s0tag, const int k_) {
+            const int k = uniform(k_);
             constexpr bool S0 = decltype(s0tag)::value;
             constexpr int nb = S0 ? 2 : 4;
             if (k + 1 < N) ld_fw<FINAL>(k + 1, nxt);
@@ -725,75 +739,131 @@ struct Lane {
         o.a_prim = -a_prim; o.a_dual = -a_dual; o.s1 = s1; o.s2 = s2; o.lin_g = lin_g;
     }
 
-    // ---- the whole RTI step of this lane ----
-    MPC_HD void rti_step() const {
-        const int N = c.N;
-        prepare();
+    // ---- the RTI step as a resumable state machine -----------------------------------------
+    // begin() -> while (cont()) iterate() -> finish().  Between iterations the per-lane scalars
+    // can be parked in the workspace (save_state / load_state), which lets the batch driver
+    // move a still-running instance to another lane slot (compaction of stragglers).
+    struct State {
+        int kk, diag;
+        double alpha, mu;
         Norms n;
-        sweep_bu<true>(0, 0.0, 0.0, n);
-        const int nc = 4 + 8 * (N - 1);
-        const double nc_inv = 1.0 / nc;
-        double mu = n.musum * nc_inv;
-        double alpha = 1.0;
-        int kk = 0, diag = 0;
-        while (kk < c.iter_max && alpha > c.alpha_min &&
-               (n.g > c.res_g_max || n.b > c.res_b_max || n.d > c.res_d_max ||
-                fabs(n.m - c.tau_min) > c.res_m_max)) {
-            // --- OCP_QP_IPM_DELTA_STEP (the factorisation was done by the last BU sweep) ---
-            FwdOut fa;
-            sweep_fw<false>(0, 0.0, fa);
-            const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
-            const double mu_aff0 = (n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nc_inv;
-            const double tmp = mu_aff0 / mu;
-            const double sigma = tmp * tmp * tmp;
-            double sigma_mu = sigma * mu;
-            if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
-            int mode = 1;
-            sweep_bw(1, sigma_mu);
-            FwdOut fc;
-            sweep_fw<true>(1, sigma_mu, fc);
+        double home;  // index of the instance this slot is working for
+    };
+    MPC_HD double nc_inv() const { return 1.0 / (4 + 8 * (c.N - 1)); }
+
+    MPC_HD void begin(State& s, size_t home) const {
+        prepare();
+        sweep_bu<true>(0, 0.0, 0.0, s.n);
+        s.mu = s.n.musum * nc_inv();
+        s.alpha = 1.0;
+        s.kk = 0;
+        s.diag = 0;
+        s.home = (double)home;
+    }
+    // loop condition of d_ocp_qp_ipm_solve
+    MPC_HD bool cont(const State& s) const {
+        return s.kk < c.iter_max && s.alpha > c.alpha_min &&
+               (s.n.g > c.res_g_max || s.n.b > c.res_b_max || s.n.d > c.res_d_max ||
+                fabs(s.n.m - c.tau_min) > c.res_m_max);
+    }
+    // one IPM iteration: OCP_QP_IPM_DELTA_STEP (the factorisation was done by the last BU
+    // sweep), UPDATE_VAR_QP, OCP_QP_RES_COMPUTE (+ the next factorisation)
+    MPC_HD void iterate(State& s) const {
+        const double nci = nc_inv();
+        FwdOut fa;
+        sweep_fw<false>(0, 0.0, fa);
+        const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
+        const double mu_aff0 = (s.n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
+        const double tmp = mu_aff0 / s.mu;
+        const double sigma = tmp * tmp * tmp;
+        double sigma_mu = sigma * s.mu;
+        if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+        int mode = 1;
+        sweep_bw(1, sigma_mu);
+        FwdOut fc;
+        sweep_fw<true>(1, sigma_mu, fc);
+        double alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
+        // conditional predictor-corrector: fall back to pure centering
+        const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
+        if (mu_aff1 > 2.0 * mu_aff0) {
+            mode = 2;
+            sweep_bw(2, sigma_mu);
+            sweep_fw<true>(2, sigma_mu, fc);
             alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
-            // conditional predictor-corrector: fall back to pure centering
-            const double mu_aff1 = (n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nc_inv;
-            if (mu_aff1 > 2.0 * mu_aff0) {
-                mode = 2;
-                sweep_bw(2, sigma_mu);
-                sweep_fw<true>(2, sigma_mu, fc);
-                alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
-            }
-            if (!(fc.lin_g < c.itref_tol_g)) diag |= MPC_DIAG_ITREF;
-            if (!(fc.lin_g < c.lq_tol)) diag |= MPC_DIAG_LQ;
-            // --- UPDATE_VAR_QP + OCP_QP_RES_COMPUTE (+ next factorisation) ---
-            double a_upd = alpha;
-            if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
-            sweep_bu<false>(mode, sigma_mu, a_upd, n);
-            mu = n.musum * nc_inv;
-            ++kk;
         }
-        // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping)
+        if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF;
+        if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;
+        s.alpha = alpha;
+        double a_upd = alpha;
+        if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
+        sweep_bu<false>(mode, sigma_mu, a_upd, s.n);
+        s.mu = s.n.musum * nci;
+        ++s.kk;
+    }
+    // per-lane scalars parked in unused rows of stage N
+    MPC_HD void save_state(const State& s) const {
+        const int N = uniform(c.N);
+        st(R_LAM, N, 0, (double)s.kk); st(R_LAM, N, 1, (double)s.diag);
+        st(R_LAM, N, 2, s.alpha); st(R_LAM, N, 3, s.mu);
+        st(R_LAM, N, 4, s.n.g); st(R_LAM, N, 5, s.n.b); st(R_LAM, N, 6, s.n.d); st(R_LAM, N, 7, s.n.m);
+        st(R_T, N, 0, s.n.musum); st(R_T, N, 1, s.home);
+    }
+    MPC_HD void load_state(State& s) const {
+        const int N = uniform(c.N);
+        s.kk = (int)ld(R_LAM, N, 0); s.diag = (int)ld(R_LAM, N, 1);
+        s.alpha = ld(R_LAM, N, 2); s.mu = ld(R_LAM, N, 3);
+        s.n.g = ld(R_LAM, N, 4); s.n.b = ld(R_LAM, N, 5); s.n.d = ld(R_LAM, N, 6); s.n.m = ld(R_LAM, N, 7);
+        s.n.musum = ld(R_T, N, 0); s.home = ld(R_T, N, 1);
+    }
+    // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping) and the
+    // full-step update, written to the instance's HOME capsule (`hm`: the handle's primary
+    // workspace), which differs from this lane's slot after a compaction.
+    MPC_HD void finish(const State& s, const Mem& hm) const {
+        const int N = uniform(c.N);
         int hs;
-        if (kk == c.iter_max) hs = 1;
-        else if (alpha <= c.alpha_min) hs = 2;
-        else if (mu != mu) hs = 3;
+        if (s.kk == c.iter_max) hs = 1;
+        else if (s.alpha <= c.alpha_min) hs = 2;
+        else if (s.mu != s.mu) hs = 3;
         else hs = 0;
         const bool ok = (hs == 0 || hs == 1);
-        m.QPITER[wbase + lane] = kk;
-        m.DIAG[wbase + lane] = diag;
-        m.STATUS[wbase + lane] = ok ? 0 : 4;
+        const size_t h = (size_t)s.home;
+        hm.QPITER[h] = s.kk;
+        hm.DIAG[h] = s.diag;
+        hm.STATUS[h] = ok ? 0 : 4;
+        double* col = reinterpret_cast<double*>(hm.slab + (h >> 6) * hm.wave_bytes) + (h & 63);
         if (ok) {
             for (int k = 0; k <= N; ++k) {
+                double* sk = col + ((size_t)(k * MPC_RPS) << 6);
                 if (k < N) {
-                    st(R_U, k, 0, ld(R_Z, k, 0)); st(R_U, k, 1, ld(R_Z, k, 1));
-                    st(R_PI, k, 0, ld(R_PIQ, k, 0)); st(R_PI, k, 1, ld(R_PIQ, k, 1));
-                    st(R_PI, k, 2, ld(R_PIQ, k, 2));
+                    sk[(R_U + 0) << 6] = ld(R_Z, k, 0); sk[(R_U + 1) << 6] = ld(R_Z, k, 1);
+                    sk[(R_PI + 0) << 6] = ld(R_PIQ, k, 0); sk[(R_PI + 1) << 6] = ld(R_PIQ, k, 1);
+                    sk[(R_PI + 2) << 6] = ld(R_PIQ, k, 2);
                 }
-                st(R_X, k, 0, ld(R_Z, k, 2)); st(R_X, k, 1, ld(R_Z, k, 3));
-                st(R_X, k, 2, ld(R_Z, k, 4));
+                sk[(R_X + 0) << 6] = ld(R_Z, k, 2); sk[(R_X + 1) << 6] = ld(R_Z, k, 3);
+                sk[(R_X + 2) << 6] = ld(R_Z, k, 4);
             }
+            double* sn = col + ((size_t)(N * MPC_RPS) << 6);
+            sn[(R_U0 + 0) << 6] = ld(R_Z, 0, 0);
+            sn[(R_U0 + 1) << 6] = ld(R_Z, 0, 1);
+        } else {
+            double* sn = col + ((size_t)(N * MPC_RPS) << 6);
+            sn[(R_U0 + 0) << 6] = col[(R_U + 0) << 6];   // previous u_0 stays in force
+            sn[(R_U0 + 1) << 6] = col[(R_U + 1) << 6];
         }
-        st(R_U0, c.N, 0, ld(R_U, 0, 0));
-        st(R_U0, c.N, 1, ld(R_U, 0, 1));
+    }
+
+    // whole step on one lane without phases (host build, small batches)
+    MPC_HD void rti_step(const Mem& hm) const {
+        State s;
+        begin(s, wbase + lane);
+        while (cont(s)) iterate(s);
+        finish(s, hm);
     }
 };
+
+// Rows of a stage that carry a running solve from one IPM iteration to the next (everything
+// else is recomputed before it is read): YREF, AB, C | Z, PIQ, LAM, T | P, KFF | RG, RB.
+// Compaction copies exactly these (two contiguous row ranges) for every stage 0..N.
+enum : int { MPC_CARRY_A0 = R_YREF, MPC_CARRY_A1 = R_KFF + 2, MPC_CARRY_B0 = R_RG, MPC_CARRY_B1 = R_RB + 3 };
 
 }  // namespace mpc

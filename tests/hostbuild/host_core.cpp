@@ -38,7 +38,7 @@ extern "C" int hostcore_rti_batch(const mpc_ocp_spec_t* spec, int B, const doubl
     for (size_t i = 0; i < (size_t)B; ++i) {
         Lane lane(c, m, i & ~(size_t)63, (unsigned)(i & 63));
         for (int q = 0; q < iters; ++q) {
-            lane.rti_step();
+            lane.rti_step(m);
             if (m.STATUS[i] != 0) break;
         }
     }
