@@ -129,6 +129,7 @@ void mpc_batch_free(mpc_batch_t* h);
  * (hipEvents on the handle's stream around the device work), horizon,
  * capacity, and the last HIP error string of this handle. */
 double mpc_batch_last_kernel_ms(mpc_batch_t* h);
+double mpc_batch_last_phase0_ms(mpc_batch_t* h); /* device time of the dense first k_phase launch */
 int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8); /* live instances entering phases 1..7 of the last solve */
 int mpc_batch_horizon(const mpc_batch_t* h);
 int mpc_batch_capacity(const mpc_batch_t* h);

@@ -24,7 +24,7 @@ EXPORTS = (
     "mpc_spec_variant", "mpc_batch_create", "mpc_batch_solve", "mpc_batch_solve_device",
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
-    "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts",
+    "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
 )
 
 
@@ -75,6 +75,8 @@ def lib():
     L.mpc_batch_last_kernel_ms.argtypes = [_vp]
     L.mpc_batch_last_kernel_ms.restype = ctypes.c_double
     L.mpc_batch_debug_phase_counts.argtypes = [_vp, _ip]
+    L.mpc_batch_last_phase0_ms.argtypes = [_vp]
+    L.mpc_batch_last_phase0_ms.restype = ctypes.c_double
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -180,6 +182,9 @@ class BatchSolver:
         out = np.zeros(8, np.int32)
         self._check(lib().mpc_batch_debug_phase_counts(self._h, _pi(out)), "mpc_batch_debug_phase_counts")
         return out
+
+    def last_phase0_ms(self):
+        return float(lib().mpc_batch_last_phase0_ms(self._h))
 
     def last_kernel_ms(self):
         return float(lib().mpc_batch_last_kernel_ms(self._h))

@@ -191,6 +191,8 @@ struct Shard {
     size_t S = 0;      // padded stride
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_ph[MPC_MAX_PHASES + 1] = {};  // boundaries of the k_phase launches of the last solve
+    int n_ph = 0;
     char* slab = nullptr;    // primary workspace: capsules (home), inputs, phase 0
     char* slab2 = nullptr;   // secondary workspace for compacted stragglers (lazily sized)
     int* islab = nullptr;
@@ -229,6 +231,7 @@ static void free_shard(Shard& s) {
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
+    for (hipEvent_t e : s.ev_ph) if (e) (void)hipEventDestroy(e);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     s = Shard();
 }
@@ -252,7 +255,10 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
     for (int it = 0; it < iters; ++it) {
         if (n <= MPC_SINGLE_PHASE_MAX || !s.slab2) {
+            HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
             hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, m, m, (const int*)nullptr, n, 1, 0, (int*)nullptr);
+            HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
+            s.n_ph = 1;
         } else {
             // phases 0..P-1; a wave hands over when fewer than MINACT of its lanes still iterate.
             // Measured on MI355X (65536 x N=50): P=2, MINACT=8 is the optimum (20.4 ms/tick vs 25.0
@@ -267,12 +273,15 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
                 const Mem& cur = (p % 2 == 0) ? m : s.mem2;
                 const Mem& oth = (p % 2 == 0) ? s.mem2 : m;
                 const bool last = (p == P - 1);
+                if (p == 0) HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
                 hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, cur, m, counts + p, n, p == 0 ? 1 : 0,
                                    last ? 0 : MINACT, flags);
+                if (p == 0) HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
                 if (!last)
                     hipLaunchKernelGGL(k_compact, wgrid, wblk, 0, st, cur, oth, counts + p, n, p == 0 ? 1 : 0, flags,
                                        counts + p + 1, N);
             }
+            s.n_ph = 1;
         }
     }
     if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
@@ -355,6 +364,7 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreate(&s.ev0));
             HIPCHK(h, hipEventCreate(&s.ev1));
+            for (int q = 0; q <= MPC_MAX_PHASES; ++q) HIPCHK(h, hipEventCreate(&s.ev_ph[q]));
             const size_t nbytes = slab_bytes_for(N, (size_t)capa);
             HIPCHK(h, hipMalloc(&s.slab, nbytes));
             HIPCHK(h, hipMalloc(&s.islab, 3 * s.S * sizeof(int)));
@@ -569,6 +579,17 @@ int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8) {
     HIPCHK(h, hipMemcpy(out8, s.phase_ints, MPC_MAX_PHASES * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipSetDevice(prev);
     return 0;
+}
+// Device time of the first (dense, HBM-bound) k_phase launch of the last solve on the first
+// shard, from HIP events on the launch stream; synchronises.  Used by bench.py for the roofline.
+double mpc_batch_last_phase0_ms(mpc_batch_t* h) {
+    if (!h || h->shards.empty()) return -1.0;
+    Shard& s = h->shards[0];
+    float ms = 0.f;
+    if (s.n_ph < 1 || hipEventSynchronize(s.ev_ph[1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, s.ev_ph[0], s.ev_ph[1]) != hipSuccess)
+        return -1.0;
+    return ms;
 }
 int mpc_batch_horizon(const mpc_batch_t* h) { return h ? h->spec.N : -1; }
 int mpc_batch_capacity(const mpc_batch_t* h) { return h ? h->capacity : -1; }

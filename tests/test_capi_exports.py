@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "mpc_batch.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mpc_(?:batch|spec)_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mpc_(?:batch|spec)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -215,3 +215,67 @@ def test_create_rejects_bad_arguments():
     with pytest.raises(capi.MpcError):
         s.solve(np.zeros((9, 3)), np.zeros((9, sp.N, 5)), np.zeros((9, 3)))  # B > capacity
     s.close()
+
+
+def test_optimizer_closed_loop_gpu():
+    """The host-side `Optimizer` mirror (mpc_amd/optimizer.py) driving the GPU library in closed
+    loop on the head of the reference's recorded path (tests/golden/*_path150_head.txt), against
+    the same loop on the oracle: same waypoint decisions, commands within 1e-6 on every tick."""
+    import os
+    from mpc_amd.optimizer import Optimizer, load_txt
+    from tests.oracle_solver import OracleSolver
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))
+    u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))
+    og = Optimizer(0.1, 40, 0.5, *s[0], state_refs=s, input_refs=u)               # GPU library
+    oo = Optimizer(0.1, 40, 0.5, *s[0], state_refs=s, input_refs=u, solver_factory=OracleSolver)
+    for k in range(120):
+        assert og.update_and_solve(og.x_current) == 0 and oo.update_and_solve(oo.x_current) == 0
+        assert og.target_waypoint_index == oo.target_waypoint_index
+        assert np.abs(og.u_current - oo.u_current).max() < TOL_HARD, k
+        og.integrate_next_states(); oo.integrate_next_states()
+        assert np.abs(og.x_current - oo.x_current).max() < TOL_HARD, k
+    d = np.hypot(s[:, 0] - og.x_current[0], s[:, 1] - og.x_current[1]).min()
+    assert d < 0.05
+    # park manoeuvre (include/optimizer.hpp:167-238) on the GPU 'park' capsule
+    xs = np.array([0.63, 0.32, 0.0, 0.0, 0.0])
+    for o in (og, oo):
+        o.x_current = np.array([3.0, 2.0, 0.05])
+        o.set_up_park(xs)
+    rc = 0
+    for k in range(400):
+        rc = og.update_and_solve_park(xs)
+        rco = oo.update_and_solve_park(xs)
+        assert rc == rco
+        if rc != 0:
+            break
+        assert np.abs(og.u_current - oo.u_current).max() < TOL_HARD, k
+        for o in (og, oo):
+            o.x_current = o._solver_park.sim_step(o.x_current.reshape(1, 3), o.u_current.reshape(1, 2))[0]
+    assert rc == 2
+    og.close()
+
+
+def test_park_full_size_properties(oracle):
+    """BASELINE config 4: 16384 park instances (N=49, soft terminal weights), cold + 2 warm ticks.
+    Size-independent properties + an oracle spot check of 256 instances on the last tick."""
+    B = 16384
+    sp, wl = workload.make("park", B)
+    solver = capi.BatchSolver(sp, B)
+    for t in range(3):
+        x0, yref, yref_e = wl.tick(t)
+        if t == 2:
+            xt_in, ut_in, _ = solver.get(B, want_pi=False)
+        r = solver.solve(x0, yref, yref_e)
+    assert (r["status"] == 0).all()
+    xt, ut, _ = solver.get(B, want_pi=False)
+    assert np.abs(xt[:, 0] - x0).max() < 1e-12                       # x0 elimination: stage 0 pinned
+    eps = 1e-7
+    assert (ut[:, :, 0] <= sp.ubu[0] + eps).all() and (ut[:, :, 0] >= sp.lbu[0] - eps).all()
+    assert (ut[:, :, 1] <= sp.ubu[1] + eps).all() and (ut[:, :, 1] >= sp.lbu[1] - eps).all()
+    assert np.array_equal(r["u0"], ut[:, 0])
+    idx = np.random.Generator(np.random.PCG64(5)).choice(B, 256, replace=False)
+    ro = oracle.rti_batch(sp, x0[idx], yref[idx], yref_e[idx], xt_in[idx], ut_in[idx])
+    rg = dict(u0=r["u0"][idx], xtraj=xt[idx], utraj=ut[idx], status=r["status"][idx], qp_iter=r["qp_iter"][idx])
+    _compare(ro, rg, 256)
+    solver.close()
