@@ -51,7 +51,8 @@ typedef struct mpc_ocp_spec {
     double W_e[3];    /* diag terminal weight on [x y psi] */
     double lbu[2], ubu[2]; /* bounds on v, delta, stages 0..N-1 (idxbu = {0,1}) */
     double lbx[2], ubx[2]; /* bounds on x, y, stages 1..N-1   (idxbx = {0,1}) */
-    int sqp_max_iter; /* 1 = SQP_RTI (the reference); >1 = repeat RTI steps until NLP residuals < nlp_tol */
+    int sqp_max_iter; /* 1 = SQP_RTI (the reference); >1 = full SQP: linearise, NLP residuals, exit if all
+                         < nlp_tol (status 0), QP, full step; status 2 (MAXITER) after sqp_max_iter QPs */
     int qp_iter_max;  /* HPIPM iter_max (50) */
     int hpipm_mode;   /* MPC_HPIPM_BALANCE */
     double nlp_tol;   /* used only when sqp_max_iter > 1 (reference JSON: 1e-6) */
@@ -124,6 +125,14 @@ int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u);
 /* Replaces mobile_robot_acados_free() + free_capsule()
  * (acados_solver_mobile_robot.c:964-993, 98-103). */
 void mpc_batch_free(mpc_batch_t* h);
+
+/* Full SQP only (sqp_max_iter > 1; BASELINE.json config 5, acados nlp_solver_type "SQP", the
+ * commented-out option at scripts/mpc_acados.py:234-235; tolerances
+ * scripts/mobile_robot_acados_ocp.json "nlp_solver_tol_*"): number of QPs solved per instance
+ * and the last NLP residuals {stat, eq, ineq, comp} of the last mpc_batch_solve*.  Replaces
+ * ocp_nlp_get(.., "sqp_iter", ..) / ocp_nlp_get(.., "res_stat", ..) ….  Host pointers, may be NULL:
+ * sqp_iter [B], res4 [B][4]. */
+int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 
 /* Introspection used by bench/tests: kernel time of the last solve in ms
  * (hipEvents on the handle's stream around the device work), horizon,

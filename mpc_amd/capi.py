@@ -25,6 +25,7 @@ EXPORTS = (
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
+    "mpc_batch_get_sqp",
 )
 
 
@@ -77,6 +78,7 @@ def lib():
     L.mpc_batch_debug_phase_counts.argtypes = [_vp, _ip]
     L.mpc_batch_last_phase0_ms.argtypes = [_vp]
     L.mpc_batch_last_phase0_ms.restype = ctypes.c_double
+    L.mpc_batch_get_sqp.argtypes = [_vp, ctypes.c_int, _ip, _dp]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -161,6 +163,13 @@ class BatchSolver:
         pi = np.zeros((B, N, 3)) if want_pi else None
         self._check(lib().mpc_batch_get(self._h, B, _p(xt), _p(ut), _p(pi)), "mpc_batch_get")
         return xt, ut, pi
+
+    def get_sqp(self, B=None):
+        """Full SQP: (sqp_iter [B], residuals [B,4] = stat, eq, ineq, comp) of the last solve."""
+        B = self.capacity if B is None else B
+        it, res = np.zeros(B, np.int32), np.zeros((B, 4))
+        self._check(lib().mpc_batch_get_sqp(self._h, B, _pi(it), _p(res)), "mpc_batch_get_sqp")
+        return it, res
 
     def reset(self, mask=None):
         if mask is None:

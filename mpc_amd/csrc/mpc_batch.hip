@@ -44,7 +44,13 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
     const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
     if (wbase >= (size_t)cnt) return;  // wave-uniform
     const unsigned l = threadIdx.x;
-    const bool valid = wbase + l < (size_t)cnt;
+    const bool inrange = wbase + l < (size_t)cnt;
+    // full SQP: instances whose residual check passed (or whose QP failed) sit this round out
+    const bool valid = inrange && !(c.sqp && first && home.ACTIVE[wbase + l] == 0);
+    if (__ballot(valid) == 0ull) {
+        if (flags && inrange) flags[wbase + l] = 0;
+        return;
+    }
     Lane lane(c, cur, wbase, l);
     Lane::State s;
     s.kk = 0; s.diag = 0; s.alpha = 0.0; s.mu = 0.0; s.home = 0.0;
@@ -64,7 +70,39 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
         if (go) lane.save_state(s);
         else lane.finish(s, home);
     }
-    if (flags && valid) flags[wbase + l] = go ? 1 : 0;
+    if (flags && inrange) flags[wbase + l] = go ? 1 : 0;
+}
+
+// Full SQP only (spec.sqp_max_iter > 1; BASELINE config 5): the head of one SQP iteration.
+// Linearises every stage of the still-active instances, evaluates the NLP residuals with the
+// multipliers of the previous QP and retires the instances that meet nlp_tol (status 0) —
+// acados ocp_nlp_sqp.c order: linearise, residuals, exit test, QP, update.  `n_active` counts
+// the instances that go on to the QP (one atomic per wave).
+__global__ __launch_bounds__(MPC_WAVE) void k_nlp_res(Consts c, Mem m, int B, int sqp_it, int* n_active) {
+    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    const unsigned l = threadIdx.x;
+    const size_t i = wbase + l;
+    const bool inrange = i < (size_t)B;
+    if (inrange && sqp_it == 0) { m.ACTIVE[i] = 1; m.SQPITER[i] = 0; m.QPITER[i] = 0; m.DIAG[i] = 0; m.STATUS[i] = 2; }
+    const bool valid = inrange && (sqp_it == 0 || m.ACTIVE[i] != 0);
+    if (__ballot(valid) == 0ull) return;
+    bool go = false;
+    if (valid) {
+        Lane lane(c, m, wbase, l);
+        double r[4];
+        lane.nlp_res_and_linearize(r);
+        for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = r[q];
+        go = !(r[0] < c.nlp_tol && r[1] < c.nlp_tol && r[2] < c.nlp_tol && r[3] < c.nlp_tol);
+        if (!go) {
+            m.ACTIVE[i] = 0;
+            m.STATUS[i] = 0;
+            const int N = c.N;
+            lane.st(R_U0, N, 0, lane.ld(R_U, 0, 0));
+            lane.st(R_U0, N, 1, lane.ld(R_U, 0, 1));
+        }
+    }
+    const int n = __popcll(__ballot(go));
+    if (n > 0 && l == 0) atomicAdd(n_active, n);
 }
 
 // Packs the instances that are still iterating (flags) densely into the other workspace.
@@ -158,8 +196,12 @@ __global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
     if (mask && !mask[i]) return;
     double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63);
     for (int k = 0; k <= N; ++k)
+    {
         for (int r = 0; r < R_YREF; ++r)  // rows R_X, R_U, R_PI are the first 8 of a stage
             blk[(size_t)(k * MPC_RPS + r) << 6] = 0.0;
+        for (int r = R_LAM; r < R_LAM + 8; ++r)  // bound multipliers (read by the full-SQP residual check)
+            blk[(size_t)(k * MPC_RPS + r) << 6] = 0.0;
+    }
 }
 
 // H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).  x [B][3], u [B][2].
@@ -193,6 +235,7 @@ struct Shard {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ph[MPC_MAX_PHASES + 1] = {};  // boundaries of the k_phase launches of the last solve
     int n_ph = 0;
+    int sqp_rounds = 0;  // QP rounds of the last full-SQP solve
     char* slab = nullptr;    // primary workspace: capsules (home), inputs, phase 0
     char* slab2 = nullptr;   // secondary workspace for compacted stragglers (lazily sized)
     int* islab = nullptr;
@@ -251,9 +294,24 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
     if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
-    const int iters = h->spec.sqp_max_iter > 1 ? h->spec.sqp_max_iter : 1;
+    const bool sqp = h->spec.sqp_max_iter > 1;
+    const int iters = sqp ? h->spec.sqp_max_iter : 1;
     const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
+    s.sqp_rounds = 0;
     for (int it = 0; it < iters; ++it) {
+        if (sqp) {
+            // head of an SQP iteration; the host reads the number of instances still iterating
+            // (one 4-byte copy + sync per iteration: full SQP is the Monte-Carlo mode, not the
+            // control-loop one) and stops as soon as every instance has retired.
+            int* n_active = s.phase_ints + MPC_MAX_PHASES - 1;   // last counter slot is never a phase count (P <= 7)
+            HIPCHK(h, hipMemsetAsync(n_active, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_nlp_res, wgrid, wblk, 0, st, h->consts, m, n, it, n_active);
+            int na = 0;
+            HIPCHK(h, hipMemcpyAsync(&na, n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (na == 0) break;
+            ++s.sqp_rounds;
+        }
         if (n <= MPC_SINGLE_PHASE_MAX || !s.slab2) {
             HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
             hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, m, m, (const int*)nullptr, n, 1, 0, (int*)nullptr);
@@ -264,7 +322,8 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
             // Measured on MI355X (65536 x N=50): P=2, MINACT=8 is the optimum (20.4 ms/tick vs 25.0
             // single-phase; more phases or an earlier hand-over cost more in compaction traffic
             // than they save).  MPC_PHASES / MPC_MIN_ACTIVE override for experiments.
-            static const int P = getenv("MPC_PHASES") ? atoi(getenv("MPC_PHASES")) : 2;
+            static const int P0 = getenv("MPC_PHASES") ? atoi(getenv("MPC_PHASES")) : 2;
+            const int P = P0 < 1 ? 1 : (P0 > MPC_MAX_PHASES - 1 ? MPC_MAX_PHASES - 1 : P0);
             static const int MINACT = getenv("MPC_MIN_ACTIVE") ? atoi(getenv("MPC_MIN_ACTIVE")) : MPC_WAVE / 8;
             int* counts = s.phase_ints;
             int* flags = s.phase_ints + MPC_MAX_PHASES;
@@ -367,9 +426,9 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             for (int q = 0; q <= MPC_MAX_PHASES; ++q) HIPCHK(h, hipEventCreate(&s.ev_ph[q]));
             const size_t nbytes = slab_bytes_for(N, (size_t)capa);
             HIPCHK(h, hipMalloc(&s.slab, nbytes));
-            HIPCHK(h, hipMalloc(&s.islab, 3 * s.S * sizeof(int)));
+            HIPCHK(h, hipMalloc(&s.islab, islab_ints_for((size_t)capa) * sizeof(int)));
             HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
-            HIPCHK(h, hipMemsetAsync(s.islab, 0, 3 * s.S * sizeof(int), s.stream));
+            HIPCHK(h, hipMemsetAsync(s.islab, 0, islab_ints_for((size_t)capa) * sizeof(int), s.stream));
             s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
             if (capa > MPC_SINGLE_PHASE_MAX) {
                 // compaction only ever moves instances that are still iterating after a wave
@@ -566,6 +625,23 @@ double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
             h->last_ms = ms;
     }
     return h->last_ms;
+}
+// Full SQP (sqp_max_iter > 1): per-instance number of QPs solved and the last NLP residuals
+// (stat, eq, ineq, comp) of the last solve.  Host pointers, either may be NULL.
+int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {
+    if (!h || B < 1 || B > h->capacity) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        if (sqp_iter) HIPCHK(h, hipMemcpy(sqp_iter + s.first, s.mem.SQPITER, sizeof(int) * n, hipMemcpyDeviceToHost));
+        if (res4) HIPCHK(h, hipMemcpy(res4 + 4 * (size_t)s.first, s.mem.NLPRES, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
 }
 // Development/diagnostic: live-instance counts at the start of phases 1..7 of the last solve
 // on the first shard (phase schedule of k_phase / k_compact).

@@ -49,6 +49,8 @@ struct Consts {
     double reg_prim, lam_min, t_min, tau_min, thr0;
     double itref_tol_g;   // lin-system residual above which HPIPM would refine (diagnostic)
     double lq_tol;        // lin-system residual above which HPIPM would switch to LQ (diagnostic)
+    int sqp;              // 1: full SQP (sqp_max_iter > 1) — k_nlp_res linearises and gates the instances
+    double nlp_tol;       // exit tolerance on the four NLP residuals (full SQP only)
 };
 
 // Workspace layout.  One contiguous block per wavefront (64 instances):
@@ -85,6 +87,8 @@ struct Mem {
     char* slab;          // n_waves blocks of wave_bytes each
     size_t wave_bytes;   // (N+1) * MPC_RPS * 512
     int *STATUS, *QPITER, *DIAG;   // [S] each
+    int *SQPITER, *ACTIVE;         // [S] each, full SQP only: QPs solved so far, still iterating
+    double* NLPRES;                // [S][4] last NLP residuals (stat, eq, ineq, comp), full SQP only
 };
 
 #define MPC_DIAG_ITREF 1  /* HPIPM's corrector refinement test would have asked for a solve */
@@ -130,7 +134,7 @@ struct Lane {
 
     // ---- H5/H7: ERK4 with forward sensitivities, structure-exploiting but with the generic
     //      integrator's operation order (entries that are structurally 0/1 are exact there too)
-    MPC_HD void linearize_stage(int k) const {
+    MPC_HD void linearize_stage(int k, double* xn_out = nullptr) const {
         const double x0 = ld(R_X, k, 0), x1 = ld(R_X, k, 1), psi = ld(R_X, k, 2);
         const double v = ld(R_U, k, 0), dl = ld(R_U, k, 1);
         const double h = c.Ts;
@@ -184,6 +188,61 @@ struct Lane {
         st(R_C, k, 0, xn0 - (x0 + a * psi) - (B00 * v + B01 * dl));
         st(R_C, k, 1, xn1 - (x1 + b * psi) - (B10 * v + B11 * dl));
         st(R_C, k, 2, xn2 - psi - (B20 * v + B21 * dl));
+        if (xn_out) { xn_out[0] = xn0; xn_out[1] = xn1; xn_out[2] = xn2; }
+    }
+
+    // ---- full SQP only (BASELINE config 5; acados ocp_nlp_sqp.c / ocp_nlp_res_compute restated,
+    //      no counterpart in the reference's SQP_RTI solvers): linearise every stage at the
+    //      iterate and evaluate the NLP residuals with the multipliers of the last QP:
+    //      out = { ||cost_grad + dyn_adj + ineq_adj||_inf (stage-0 state rows excluded),
+    //              ||phi(x_k,u_k) - x_{k+1}||_inf, max(0, lb - z, z - ub, |x_0 - x0bar|),
+    //              max |lam_j * violation_j| }.
+    MPC_HD void nlp_res_and_linearize(double out[4]) const {
+        const int N = uniform(c.N);
+        double r_stat = 0.0, r_eq = 0.0, r_ineq = 0.0, r_comp = 0.0;
+        for (int i = 0; i < 3; ++i) r_ineq = amax(r_ineq, ld(R_X0, N, i) - ld(R_X, 0, i));
+        double pim0 = 0.0, pim1 = 0.0, pim2 = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            double z[5], g[5];
+            z[0] = (k < N) ? ld(R_U, k, 0) : 0.0;
+            z[1] = (k < N) ? ld(R_U, k, 1) : 0.0;
+            z[2] = ld(R_X, k, 0); z[3] = ld(R_X, k, 1); z[4] = ld(R_X, k, 2);
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) g[i] = c.wg[i] * (z[i] - ld(R_YREF, k, i < 2 ? 3 + i : i - 2));
+            } else {
+                g[0] = g[1] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) g[2 + i] = c.we[i] * (z[2 + i] - ld(R_YREFE, N, i));
+            }
+            if (k > 0) { g[2] -= pim0; g[3] -= pim1; g[4] -= pim2; }
+            if (k < N) {
+                const int nb = (k == 0) ? 2 : 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nb) {
+                        const double dl = c.lb[j] - z[j], du = z[j] - c.ub[j];
+                        const double ll = ld(R_LAM, k, j), lu = ld(R_LAM, k, 4 + j);
+                        g[j] += lu - ll;
+                        r_ineq = fmax(r_ineq, dl); r_ineq = fmax(r_ineq, du);
+                        r_comp = amax(r_comp, ll * dl); r_comp = amax(r_comp, lu * du);
+                    }
+                }
+                double xn[3];
+                linearize_stage(k, xn);
+                const AB8 ab = ld_ab(k);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r_eq = amax(r_eq, xn[j] - ld(R_X, k + 1, j));
+                const double p0 = ld(R_PI, k, 0), p1 = ld(R_PI, k, 1), p2 = ld(R_PI, k, 2);
+                g[0] += ab.B00 * p0 + ab.B10 * p1 + ab.B20 * p2;
+                g[1] += ab.B01 * p0 + ab.B11 * p1 + ab.B21 * p2;
+                g[2] += p0; g[3] += p1; g[4] += ab.a * p0 + ab.b * p1 + p2;
+                pim0 = p0; pim1 = p1; pim2 = p2;
+            }
+            if (k < N) { r_stat = amax(r_stat, g[0]); r_stat = amax(r_stat, g[1]); }
+            if (k > 0) { r_stat = amax(r_stat, g[2]); r_stat = amax(r_stat, g[3]); r_stat = amax(r_stat, g[4]); }
+        }
+        out[0] = r_stat; out[1] = r_eq; out[2] = r_ineq; out[3] = r_comp;
     }
 
     // ---- small value types (kept in registers) ----
@@ -328,7 +387,7 @@ struct Lane {
     MPC_SWEEP void prepare() const {
         const int N = uniform(c.N);
         for (int k = 0; k <= N; ++k) {
-            if (k < N) linearize_stage(k);
+            if (k < N && !c.sqp) linearize_stage(k);   // full SQP: k_nlp_res has done it
             double z[5];
             z[0] = (k < N) ? ld(R_U, k, 0) : 0.0;
             z[1] = (k < N) ? ld(R_U, k, 1) : 0.0;
@@ -829,7 +888,11 @@ struct Lane {
         const size_t h = (size_t)s.home;
         hm.QPITER[h] = s.kk;
         hm.DIAG[h] = s.diag;
-        hm.STATUS[h] = ok ? 0 : 4;
+        hm.STATUS[h] = ok ? (c.sqp ? 2 : 0) : 4;   // full SQP: MAXITER until a residual check passes
+        if (c.sqp) {
+            hm.SQPITER[h] = hm.SQPITER[h] + 1;
+            if (!ok) hm.ACTIVE[h] = 0;
+        }
         double* col = reinterpret_cast<double*>(hm.slab + (h >> 6) * hm.wave_bytes) + (h & 63);
         if (ok) {
             for (int k = 0; k <= N; ++k) {
@@ -841,6 +904,10 @@ struct Lane {
                 }
                 sk[(R_X + 0) << 6] = ld(R_Z, k, 2); sk[(R_X + 1) << 6] = ld(R_Z, k, 3);
                 sk[(R_X + 2) << 6] = ld(R_Z, k, 4);
+                if (c.sqp && k < N) {   // the QP's bound multipliers become the NLP's (next residual check)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sk[(R_LAM + j) << 6] = ld(R_LAM, k, j);
+                }
             }
             double* sn = col + ((size_t)(N * MPC_RPS) << 6);
             sn[(R_U0 + 0) << 6] = ld(R_Z, 0, 0);

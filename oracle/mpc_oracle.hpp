@@ -900,4 +900,97 @@ inline int rti_step(const mpc_ocp_spec_t& spec, RtiWork<T>& w, const T x0bar[3],
     return MPC_SUCCESS;
 }
 
+
+// ---- full SQP (BASELINE config 5; no counterpart in the reference's generated solvers, which
+//      are all SQP_RTI — restated from acados' ocp_nlp_sqp.c / ocp_nlp_res_compute:
+//      for it < max_iter { linearise; residuals; if all < tol return SUCCESS; QP (cold start);
+//      QP failure -> QP_FAILURE; full step incl. multipliers } return MAXITER).
+// Residuals at (x, u, pi, lam):  stat = || cost_grad + dyn_adj + ineq_adj ||_inf (stage-0 state
+// rows excluded: x0 is eliminated), eq = || phi(x_k,u_k) - x_{k+1} ||_inf,
+// ineq = max(0, lb - z, z - ub, |x_0 - x0bar|), comp = max |lam_j * (bound violation)_j|.
+// lam [(N+1)*8]: lower (v, delta, x, y), upper (...), zero where a stage has no such bound.
+template <class T>
+inline void nlp_residuals(const mpc_ocp_spec_t& spec, const T x0bar[3], const T* yref, const T* yref_e,
+                          const T* xtraj, const T* utraj, const T* pi, const T* lam, T out[4]) {
+    using std::fabs; using std::sqrt;
+    const int N = spec.N;
+    const ModelConst<T> mc = model_const<T>(spec.L);
+    const T h = T(spec.Ts);
+    T r_stat = T(0.0), r_eq = T(0.0), r_ineq = T(0.0), r_comp = T(0.0);
+    auto amax = [](T& m, T v) { T a = fabs(v); if (a > m) m = a; };
+    T wc[5], wce[3];
+    for (int i = 0; i < 5; ++i) wc[i] = sqrt(T(spec.W[i]));
+    for (int i = 0; i < 3; ++i) wce[i] = sqrt(T(spec.W_e[i]));
+    const int y_of_var[5] = {3, 4, 0, 1, 2};
+    for (int i = 0; i < 3; ++i) amax(r_ineq, x0bar[i] - xtraj[i]);
+    for (int k = 0; k <= N; ++k) {
+        T g[5] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
+        if (k < N) {
+            for (int i = 0; i < 5; ++i) {
+                const int yi = y_of_var[i];
+                const T zi = (i < 2) ? utraj[2 * k + i] : xtraj[3 * k + (i - 2)];
+                g[i] = (wc[yi] * (wc[yi] * (zi - yref[5 * k + yi]))) * h;
+            }
+        } else {
+            for (int i = 0; i < 3; ++i) g[2 + i] = wce[i] * (wce[i] * (xtraj[3 * N + i] - yref_e[i]));
+        }
+        if (k > 0) for (int i = 0; i < 3; ++i) g[2 + i] = g[2 + i] - pi[3 * (k - 1) + i];
+        if (k < N) {
+            const int nb = (k == 0) ? 2 : 4;
+            for (int j = 0; j < nb; ++j) {
+                const T z = (j < 2) ? utraj[2 * k + j] : xtraj[3 * k + (j - 2)];
+                const T lo = (j < 2) ? T(spec.lbu[j]) : T(spec.lbx[j - 2]);
+                const T up = (j < 2) ? T(spec.ubu[j]) : T(spec.ubx[j - 2]);
+                const T dl = lo - z, du = z - up;
+                g[j] = g[j] + (lam[8 * k + 4 + j] - lam[8 * k + j]);
+                if (dl > r_ineq) r_ineq = dl;
+                if (du > r_ineq) r_ineq = du;
+                amax(r_comp, lam[8 * k + j] * dl);
+                amax(r_comp, lam[8 * k + 4 + j] * du);
+            }
+            T xn[3], A[9], B[6];
+            erk4_forw(mc, h, xtraj + 3 * k, utraj + 2 * k, xn, A, B);
+            for (int j = 0; j < 3; ++j) amax(r_eq, xn[j] - xtraj[3 * (k + 1) + j]);
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 3; ++j) g[i] = g[i] + B[j + 3 * i] * pi[3 * k + j];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) g[2 + i] = g[2 + i] + A[j + 3 * i] * pi[3 * k + j];
+        }
+        for (int i = (k == 0 ? 0 : 0); i < 5; ++i) {
+            if (k == 0 && i >= 2) continue;  // eliminated
+            if (k == N && i < 2) continue;   // no controls at the terminal stage
+            amax(r_stat, g[i]);
+        }
+    }
+    out[0] = r_stat; out[1] = r_eq; out[2] = r_ineq; out[3] = r_comp;
+}
+
+// xtraj/utraj/pi/lam in/out.  Returns acados status; *sqp_iter = QPs solved; res4 = the last
+// residuals evaluated.
+template <class T>
+inline int sqp_solve(const mpc_ocp_spec_t& spec, RtiWork<T>& w, const T x0bar[3], const T* yref, const T* yref_e,
+                     T* xtraj, T* utraj, T* pi, T* lam, int* sqp_iter, int* qp_iter, T res4[4]) {
+    const int N = spec.N;
+    int it = 0;
+    if (qp_iter) *qp_iter = 0;
+    for (; it < spec.sqp_max_iter; ++it) {
+        nlp_residuals<T>(spec, x0bar, yref, yref_e, xtraj, utraj, pi, lam, res4);
+        const double tol = spec.nlp_tol;
+        if (to_double(res4[0]) < tol && to_double(res4[1]) < tol && to_double(res4[2]) < tol && to_double(res4[3]) < tol) {
+            if (sqp_iter) *sqp_iter = it;
+            return MPC_SUCCESS;
+        }
+        RtiDebug<T> dbg;
+        IpmStats st;
+        const int rc = rti_step<T>(spec, w, x0bar, yref, yref_e, xtraj, utraj, pi, qp_iter, &st, &dbg);
+        if (rc != MPC_SUCCESS) {
+            if (sqp_iter) *sqp_iter = it + 1;
+            return rc;
+        }
+        for (int i = 0; i < 8 * (N + 1); ++i) lam[i] = dbg.lam[i];
+    }
+    if (sqp_iter) *sqp_iter = it;
+    return MPC_MAXITER;
+}
+
 }  // namespace mpc_oracle

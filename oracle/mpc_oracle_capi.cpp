@@ -71,7 +71,7 @@ void oracle_sim_step(const mpc_ocp_spec_t* spec, int B, double* x, const double*
     }
 }
 
-// H4/H15: one SQP-RTI step per instance (or up to sqp_max_iter steps), AoS like the C-ABI.
+// H4/H15: one SQP-RTI step per instance (sqp_max_iter is ignored: see oracle_sqp_batch), AoS like the C-ABI.
 // xtraj [B][N+1][3], utraj [B][N][2], pi [B][N][3] in/out (pi may be NULL);
 // u0 [B][2], status [B], qp_iter [B] out (may be NULL);
 // stats [B][8] out or NULL: {iter, hpipm_status, lq_switch, itref_solves, cond_pc_fallbacks,
@@ -98,12 +98,8 @@ int oracle_rti_batch(const mpc_ocp_spec_t* spec, int B, const double* x0, const 
             double* pp = pi ? pi + (size_t)i * N * 3 : pitmp.data();
             int it = 0, st = 0;
             IpmStats s;
-            const int iters = spec->sqp_max_iter > 1 ? spec->sqp_max_iter : 1;
-            for (int q = 0; q < iters; ++q) {
-                st = rti_step<double>(*spec, w, x0 + 3 * i, yref + (size_t)i * N * 5, yref_e + 3 * i, xt, ut,
-                                      pp, &it, &s);
-                if (st != MPC_SUCCESS) break;
-            }
+            st = rti_step<double>(*spec, w, x0 + 3 * i, yref + (size_t)i * N * 5, yref_e + 3 * i, xt, ut,
+                                  pp, &it, &s);
             if (u0) { u0[2 * i] = ut[0]; u0[2 * i + 1] = ut[1]; }
             if (status) status[i] = st;
             if (qp_iter) qp_iter[i] = it;
@@ -113,6 +109,45 @@ int oracle_rti_batch(const mpc_ocp_spec_t* spec, int B, const double* x0, const 
                 o[4] = s.cond_pc_fallbacks; o[5] = s.max_lin_res_fact; o[6] = s.max_lin_res_corr;
                 o[7] = s.mu_final;
             }
+        }
+    }
+    return 0;
+}
+
+// Full SQP per instance (config 5).  lam [B][N+1][8] in/out (may be NULL = zeros, not returned);
+// sqp_iter [B], res [B][4] out (may be NULL).
+int oracle_sqp_batch(const mpc_ocp_spec_t* spec, int B, const double* x0, const double* yref,
+                     const double* yref_e, double* xtraj, double* utraj, double* pi, double* lam, double* u0,
+                     int* status, int* sqp_iter, int* qp_iter, double* res, int nthreads) {
+    const int N = spec->N;
+    if (N < 1 || N > MPC_MAX_N || B < 0) return -1;
+    const IpmArg arg = make_arg(spec);
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        RtiWork<double> w(N, arg);
+        std::vector<double> pitmp(3 * N), lamtmp(8 * (N + 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int i = 0; i < B; ++i) {
+            double* xt = xtraj + (size_t)i * (N + 1) * 3;
+            double* ut = utraj + (size_t)i * N * 2;
+            double* pp = pi ? pi + (size_t)i * N * 3 : pitmp.data();
+            double* ll = lam ? lam + (size_t)i * (N + 1) * 8 : lamtmp.data();
+            if (!pi) std::fill(pitmp.begin(), pitmp.end(), 0.0);
+            if (!lam) std::fill(lamtmp.begin(), lamtmp.end(), 0.0);
+            int sit = 0, qit = 0;
+            double r4[4];
+            const int st = sqp_solve<double>(*spec, w, x0 + 3 * i, yref + (size_t)i * N * 5, yref_e + 3 * i, xt, ut,
+                                             pp, ll, &sit, &qit, r4);
+            if (u0) { u0[2 * i] = ut[0]; u0[2 * i + 1] = ut[1]; }
+            if (status) status[i] = st;
+            if (sqp_iter) sqp_iter[i] = sit;
+            if (qp_iter) qp_iter[i] = qit;
+            if (res) for (int j = 0; j < 4; ++j) res[4 * (size_t)i + j] = r4[j];
         }
     }
     return 0;

@@ -12,13 +12,14 @@ using namespace mpc;
 
 extern "C" int hostcore_rti_batch(const mpc_ocp_spec_t* spec, int B, const double* x0, const double* yref,
                                   const double* yref_e, double* xtraj, double* utraj, double* pi, double* u0,
-                                  int* status, int* qp_iter, int* diag) {
+                                  int* status, int* qp_iter, int* diag, double* lam, int* sqp_iter, double* res4) {
     if (!spec_valid(spec) || B < 1) return -1;
     const int N = spec->N;
     const Consts c = make_consts(*spec);
     const size_t S = n_waves_for(B) * 64;
     std::vector<double> slab(slab_bytes_for(N, B) / sizeof(double), 0.0);
-    std::vector<int> islab(3 * S, 0);
+    std::vector<int> islab(islab_ints_for(B), 0);
+    (void)S;
     Mem m = make_mem(reinterpret_cast<char*>(slab.data()), islab.data(), B, N);
     double* D = slab.data();
     for (size_t i = 0; i < (size_t)B; ++i) {
@@ -30,16 +31,30 @@ extern "C" int hostcore_rti_batch(const mpc_ocp_spec_t* spec, int B, const doubl
             for (int q = 0; q < 5; ++q) D[slab_index(m, i, k, R_YREF + q)] = yref[((size_t)i * N + k) * 5 + q];
             for (int q = 0; q < 2; ++q) D[slab_index(m, i, k, R_U + q)] = utraj[((size_t)i * N + k) * 2 + q];
             if (pi) for (int q = 0; q < 3; ++q) D[slab_index(m, i, k, R_PI + q)] = pi[((size_t)i * N + k) * 3 + q];
+            if (lam) for (int q = 0; q < 8; ++q) D[slab_index(m, i, k, R_LAM + q)] = lam[((size_t)i * (N + 1) + k) * 8 + q];
         }
         for (int k = 0; k <= N; ++k)
             for (int q = 0; q < 3; ++q) D[slab_index(m, i, k, R_X + q)] = xtraj[((size_t)i * (N + 1) + k) * 3 + q];
     }
-    const int iters = spec->sqp_max_iter > 1 ? spec->sqp_max_iter : 1;
     for (size_t i = 0; i < (size_t)B; ++i) {
         Lane lane(c, m, i & ~(size_t)63, (unsigned)(i & 63));
-        for (int q = 0; q < iters; ++q) {
+        if (!c.sqp) {
             lane.rti_step(m);
-            if (m.STATUS[i] != 0) break;
+            continue;
+        }
+        // full SQP: the per-instance sequence of k_nlp_res + k_phase rounds of mpc_batch.hip
+        m.ACTIVE[i] = 1; m.SQPITER[i] = 0; m.QPITER[i] = 0; m.STATUS[i] = 2;
+        for (int it = 0; it < spec->sqp_max_iter && m.ACTIVE[i]; ++it) {
+            double r[4];
+            lane.nlp_res_and_linearize(r);
+            for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = r[q];
+            if (r[0] < c.nlp_tol && r[1] < c.nlp_tol && r[2] < c.nlp_tol && r[3] < c.nlp_tol) {
+                m.ACTIVE[i] = 0; m.STATUS[i] = 0;
+                lane.st(R_U0, N, 0, lane.ld(R_U, 0, 0));
+                lane.st(R_U0, N, 1, lane.ld(R_U, 0, 1));
+                break;
+            }
+            lane.rti_step(m);
         }
     }
     for (size_t i = 0; i < (size_t)B; ++i) {
@@ -53,6 +68,11 @@ extern "C" int hostcore_rti_batch(const mpc_ocp_spec_t* spec, int B, const doubl
         if (status) status[i] = m.STATUS[i];
         if (qp_iter) qp_iter[i] = m.QPITER[i];
         if (diag) diag[i] = m.DIAG[i];
+        if (sqp_iter) sqp_iter[i] = m.SQPITER[i];
+        if (res4) for (int q = 0; q < 4; ++q) res4[4 * i + q] = m.NLPRES[4 * i + q];
+        if (lam)
+            for (int k = 0; k < N; ++k)
+                for (int q = 0; q < 8; ++q) lam[((size_t)i * (N + 1) + k) * 8 + q] = D[slab_index(m, i, k, R_LAM + q)];
     }
     return 0;
 }

@@ -50,6 +50,8 @@ def lib():
         L.oracle_rti_batch.argtypes = [ctypes.POINTER(OcpSpec), ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
                                        _dp, _ip, _ip, _dp, ctypes.c_int]
         L.oracle_rti_batch.restype = ctypes.c_int
+        L.oracle_sqp_batch.argtypes = [ctypes.POINTER(OcpSpec), ctypes.c_int] + [_dp] * 8 + [_ip, _ip, _ip, _dp, ctypes.c_int]
+        L.oracle_sqp_batch.restype = ctypes.c_int
         L.oracle_rti_debug.argtypes = [ctypes.POINTER(OcpSpec)] + [_dp] * 14 + [_ip, _dp]
         L.oracle_rti_debug.restype = ctypes.c_int
         L.oracle_count_ops.argtypes = [ctypes.POINTER(OcpSpec), _dp, _dp, _dp, _dp, _dp, _dp, _ip]
@@ -112,6 +114,26 @@ def rti_batch(spec, x0, yref, yref_e, xtraj=None, utraj=None, nthreads=0, want_s
     if want_stats:
         out["stats"] = stats
     return out
+
+
+def sqp_batch(spec, x0, yref, yref_e, xtraj=None, utraj=None, pi=None, lam=None, nthreads=0):
+    """Full SQP per instance (spec.sqp_max_iter, spec.nlp_tol).  Returns dict(u0, xtraj, utraj, pi, lam,
+    status, sqp_iter, qp_iter, res [B,4] = stat, eq, ineq, comp)."""
+    B, N = x0.shape[0], spec.N
+    x0 = np.ascontiguousarray(x0, float)
+    yref = np.ascontiguousarray(yref, float)
+    yref_e = np.ascontiguousarray(yref_e, float)
+    xt = np.zeros((B, N + 1, 3)) if xtraj is None else np.ascontiguousarray(xtraj, float).copy()
+    ut = np.zeros((B, N, 2)) if utraj is None else np.ascontiguousarray(utraj, float).copy()
+    pp = np.zeros((B, N, 3)) if pi is None else np.ascontiguousarray(pi, float).copy()
+    ll = np.zeros((B, N + 1, 8)) if lam is None else np.ascontiguousarray(lam, float).copy()
+    u0 = np.zeros((B, 2))
+    status, sit, qit = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    res = np.zeros((B, 4))
+    rc = lib().oracle_sqp_batch(ctypes.byref(spec), B, _p(x0), _p(yref), _p(yref_e), _p(xt), _p(ut), _p(pp), _p(ll),
+                                _p(u0), _pi(status), _pi(sit), _pi(qit), _p(res), nthreads)
+    assert rc == 0
+    return dict(u0=u0, xtraj=xt, utraj=ut, pi=pp, lam=ll, status=status, sqp_iter=sit, qp_iter=qit, res=res)
 
 
 def rti_debug(spec, x0, yref, yref_e, xtraj=None, utraj=None):

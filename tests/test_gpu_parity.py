@@ -279,3 +279,34 @@ def test_park_full_size_properties(oracle):
     rg = dict(u0=r["u0"][idx], xtraj=xt[idx], utraj=ut[idx], status=r["status"][idx], qp_iter=r["qp_iter"][idx])
     _compare(ro, rg, 256)
     solver.close()
+
+
+@pytest.mark.parametrize("name,B", [("mobile_robot", 3000), ("park", 300)])
+def test_full_sqp_matches_oracle(oracle, name, B):
+    """BASELINE config 5 (scaled down): sqp_max_iter > 1 = acados-style full SQP with an NLP
+    residual exit test.  Same status, same number of QPs, trajectories within the parity bar.
+    B = 3000 exercises the phased/compacted path inside every SQP round."""
+    sp, wl = workload.make(name, B, sqp_max_iter=20, nlp_tol=1e-5)
+    x0, yref, yref_e = wl.tick(0)
+    ro = oracle.sqp_batch(sp, x0, yref, yref_e)
+    solver = capi.BatchSolver(sp, B)
+    rg = solver.solve(x0, yref, yref_e)
+    sit, res = solver.get_sqp(B)
+    xg, ug, pig = solver.get(B)
+    assert np.array_equal(ro["status"], rg["status"])
+    assert (ro["sqp_iter"] == sit).mean() >= 0.995
+    same = ro["sqp_iter"] == sit
+    assert np.abs(ro["utraj"] - ug)[same].max() < TOL_PATH and np.abs(ro["xtraj"] - xg)[same].max() < TOL_PATH
+    assert np.abs(ro["utraj"] - ug).max() < 1e-4          # an instance that stops one QP apart is still at the tolerance
+    assert np.abs(ro["res"] - res)[same].max() < 1e-9
+    assert np.array_equal(rg["u0"], ug[:, 0])
+    # second call, next window: multipliers carried inside the capsule
+    x0, yref, yref_e = wl.tick(1)
+    ro2 = oracle.sqp_batch(sp, x0, yref, yref_e, ro["xtraj"], ro["utraj"], ro["pi"], ro["lam"])
+    rg2 = solver.solve(x0, yref, yref_e)
+    sit2, _ = solver.get_sqp(B)
+    s2 = same & (ro2["sqp_iter"] == sit2)
+    assert s2.mean() >= 0.99
+    assert np.array_equal(ro2["status"][s2], rg2["status"][s2])
+    assert np.abs(ro2["u0"] - rg2["u0"])[s2].max() < TOL_PATH
+    solver.close()
