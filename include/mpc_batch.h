@@ -126,6 +126,29 @@ int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u);
  * (acados_solver_mobile_robot.c:964-993, 98-103). */
 void mpc_batch_free(mpc_batch_t* h);
 
+/* ---- Closed loop on the device -----------------------------------------
+ * B vehicles following one shared path, every tick entirely on the GPU: waypoint-window
+ * selection, reference packing, the solve, the plant step.  Replaces the offline loop
+ * Optimizer::run (src/optimizer.cpp:177-206) = per tick Optimizer::update_and_solve
+ * (:208-319, with find_next_waypoint :384-431 and find_closest_waypoint :343-382) +
+ * Optimizer::integrate_next_states (:321-341), for B independent Optimizer objects at once. */
+
+/* Replaces the path loading of Optimizer::Optimizer (src/optimizer.cpp:138-160):
+ * state_refs [M][3] (x, y, psi), input_refs [Mi][2] (v, delta), host pointers, copied. */
+int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, int Mi, const double* input_refs);
+
+/* Replaces Optimizer::Optimizer(T, N, v_ref, x_init, y_init, yaw_init) (src/optimizer.cpp:20-176)
+ * for B vehicles: x_init [B][3]; waypoint indices, counters and commands start at zero;
+ * density = 1/T/v_ref, window limit = floor(3.95 / (min(v_ref, 0.35 if v_ref > 0.3) * T)).
+ * Does not touch the capsules' iterates (use mpc_batch_reset for that). */
+int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, double v_ref);
+
+/* Runs n_ticks control ticks for the first B vehicles and returns, after the last tick (any
+ * pointer may be NULL): x [B][3] state, u [B][2] command in force (the previous one where the
+ * solver failed, src/optimizer.cpp:290-293), target [B] target_waypoint_index, status [B].
+ * Blocking. */
+int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u, int* target, int* status);
+
 /* Full SQP only (sqp_max_iter > 1; BASELINE.json config 5, acados nlp_solver_type "SQP", the
  * commented-out option at scripts/mpc_acados.py:234-235; tolerances
  * scripts/mobile_robot_acados_ocp.json "nlp_solver_tol_*"): number of QPs solved per instance

@@ -25,7 +25,7 @@ EXPORTS = (
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
-    "mpc_batch_get_sqp",
+    "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run",
 )
 
 
@@ -79,6 +79,9 @@ def lib():
     L.mpc_batch_last_phase0_ms.argtypes = [_vp]
     L.mpc_batch_last_phase0_ms.restype = ctypes.c_double
     L.mpc_batch_get_sqp.argtypes = [_vp, ctypes.c_int, _ip, _dp]
+    L.mpc_batch_track_set_path.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_int, _dp]
+    L.mpc_batch_track_init.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]
+    L.mpc_batch_track_run.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -170,6 +173,28 @@ class BatchSolver:
         it, res = np.zeros(B, np.int32), np.zeros((B, 4))
         self._check(lib().mpc_batch_get_sqp(self._h, B, _pi(it), _p(res)), "mpc_batch_get_sqp")
         return it, res
+
+    # ---- closed loop on the device: B `Optimizer`s following one shared path ----
+    def track_set_path(self, state_refs, input_refs):
+        s = np.ascontiguousarray(state_refs, np.float64)
+        u = np.ascontiguousarray(input_refs, np.float64)
+        if s.ndim != 2 or s.shape[1] != 3 or u.ndim != 2 or u.shape[1] != 2:
+            raise ValueError("expected state_refs [M,3], input_refs [Mi,2]")
+        self._check(lib().mpc_batch_track_set_path(self._h, s.shape[0], _p(s), u.shape[0], _p(u)), "mpc_batch_track_set_path")
+
+    def track_init(self, x_init, T, v_ref):
+        x = np.ascontiguousarray(x_init, np.float64)
+        if x.ndim != 2 or x.shape[1] != 3 or x.shape[0] > self.capacity:
+            raise ValueError("expected x_init [B,3], B <= capacity")
+        self._track_B = x.shape[0]
+        self._check(lib().mpc_batch_track_init(self._h, x.shape[0], _p(x), T, v_ref), "mpc_batch_track_init")
+
+    def track_run(self, n_ticks):
+        B = self._track_B
+        x, u = np.zeros((B, 3)), np.zeros((B, 2))
+        target, status = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        self._check(lib().mpc_batch_track_run(self._h, B, n_ticks, _p(x), _p(u), _pi(target), _pi(status)), "mpc_batch_track_run")
+        return dict(x=x, u=u, target=target, status=status)
 
     def reset(self, mask=None):
         if mask is None:

@@ -204,12 +204,8 @@ __global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
     }
 }
 
-// H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).  x [B][3], u [B][2].
-__global__ void k_sim_step(Consts c, double* x, const double* u, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    const double x0 = x[3 * i], x1 = x[3 * i + 1], psi = x[3 * i + 2];
-    const double v = u[2 * i], dl = u[2 * i + 1];
+// H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).
+__device__ __forceinline__ void plant_step(const Consts& c, double& x0, double& x1, double& psi, double v, double dl) {
     const double h = c.Ts;
     const double om = (v / c.L) * tan(dl);
     const double ah = 0.5 * h, a1 = 1.0 * h;
@@ -218,9 +214,105 @@ __global__ void k_sim_step(Consts c, double* x, const double* u, int B) {
     sincos(psi, &sA, &cA);
     sincos(psi + ah * om, &sB, &cB);
     sincos(psi + a1 * om, &sD, &cD);
-    x[3 * i] = (((x0 + bw0 * (v * cA)) + bw1 * (v * cB)) + bw1 * (v * cB)) + bw0 * (v * cD);
-    x[3 * i + 1] = (((x1 + bw0 * (v * sA)) + bw1 * (v * sB)) + bw1 * (v * sB)) + bw0 * (v * sD);
-    x[3 * i + 2] = (((psi + bw0 * om) + bw1 * om) + bw1 * om) + bw0 * om;
+    const double n0 = (((x0 + bw0 * (v * cA)) + bw1 * (v * cB)) + bw1 * (v * cB)) + bw0 * (v * cD);
+    const double n1 = (((x1 + bw0 * (v * sA)) + bw1 * (v * sB)) + bw1 * (v * sB)) + bw0 * (v * sD);
+    const double n2 = (((psi + bw0 * om) + bw1 * om) + bw1 * om) + bw0 * om;
+    x0 = n0; x1 = n1; psi = n2;
+}
+
+// x [B][3] in/out, u [B][2].
+__global__ void k_sim_step(Consts c, double* x, const double* u, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double x0 = x[3 * i], x1 = x[3 * i + 1], psi = x[3 * i + 2];
+    plant_step(c, x0, x1, psi, u[2 * i], u[2 * i + 1]);
+    x[3 * i] = x0; x[3 * i + 1] = x1; x[3 * i + 2] = psi;
+}
+
+// ---- closed loop on the device: H2 + the packing half of H1 + H16 --------
+// Per-vehicle tracker state; one shared path table (state_refs [M][3], input_refs [Mi][2]).
+struct Track {
+    const double* sref;   // [M][3]
+    const double* iref;   // [Mi][2]
+    int M, Mi;
+    double* x;            // [S][3] current state (Optimizer::x_current)
+    double* u;            // [S][2] command in force (Optimizer::u_current)
+    int* idx;             // [S][4] target_waypoint_index, last_waypoint_index, closest_waypoint_index, count
+    double density;       // 1 / T / v_ref                     (src/optimizer.cpp:128)
+    int limit;            // floor(3.95 / (v_ref * T))         (src/optimizer.cpp:387-391)
+    int lookahead;        // 1
+};
+
+// Optimizer::find_closest_waypoint (src/optimizer.cpp:343-382): downward scan, strict '<'.
+__device__ __forceinline__ int closest_waypoint(const Track& tr, double cx, double cy, int min_index, int max_index,
+                                                int last, int target) {
+    if (min_index < 0) min_index = last < tr.M - 1 ? last : tr.M - 1;
+    if (max_index < 0) max_index = target + tr.limit < tr.M - 1 ? target + tr.limit : tr.M - 1;
+    const double cn = cx * cx + cy * cy;
+    double best = 1.7976931348623157e308;
+    int closest = -1;
+    for (int i = max_index; i >= min_index; --i) {
+        const double px = tr.sref[3 * i], py = tr.sref[3 * i + 1];
+        const double d = (px * px + py * py) - 2 * (px * cx + py * cy) + cn;
+        if (d < best) { best = d; closest = i; }
+    }
+    return closest;
+}
+
+// One thread per vehicle: Optimizer::find_next_waypoint (src/optimizer.cpp:384-431) and the
+// reference packing of Optimizer::update_and_solve (:240-281), written straight into the
+// workspace rows the solve reads (R_YREF, R_YREFE, R_X0) — no AoS staging, no host round trip.
+__global__ __launch_bounds__(MPC_WAVE) void k_track_select(Consts c, Mem m, Track tr, int B) {
+    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    const unsigned l = threadIdx.x;
+    const size_t i = wbase + l;
+    if (i >= (size_t)B) return;
+    const double cx = tr.x[3 * i], cy = tr.x[3 * i + 1], cpsi = tr.x[3 * i + 2];
+    int target = tr.idx[4 * i], last = tr.idx[4 * i + 1], count = tr.idx[4 * i + 3];
+    int closest = closest_waypoint(tr, cx, cy, -1, -1, last, target);
+    if (closest < 0) closest = last < tr.M - 1 ? last : tr.M - 1;   // empty window (the reference would index -1)
+    const double dx = tr.sref[3 * closest] - cx, dy = tr.sref[3 * closest + 1] - cy;
+    const double dist = sqrt(dx * dx + dy * dy);
+    if (dist > 1.2) {
+        const double lo = (double)closest - dist * tr.density * 1.2;
+        const int min_index = (int)(lo > 0.0 ? lo : 0.0);
+        const int c2 = closest_waypoint(tr, cx, cy, min_index, -1, last, target);
+        if (c2 >= 0) closest = c2;
+    }
+    if (count >= 8) { target = closest + tr.lookahead; count = 0; }
+    else { target = target + 1; count = count + 1; }
+    if (target > tr.M - 1) target = tr.M - 1;
+    tr.idx[4 * i] = target; tr.idx[4 * i + 1] = target; tr.idx[4 * i + 2] = closest; tr.idx[4 * i + 3] = count;
+    Lane lane(c, m, wbase, l);
+    const int N = c.N;
+    for (int j = 0; j < N; ++j) {
+        const bool past = target + j >= tr.M;
+        const int r = past ? tr.M - 1 : target + j;
+        lane.st(R_YREF, j, 0, tr.sref[3 * r]); lane.st(R_YREF, j, 1, tr.sref[3 * r + 1]); lane.st(R_YREF, j, 2, tr.sref[3 * r + 2]);
+        lane.st(R_YREF, j, 3, (past || r >= tr.Mi) ? 0.0 : tr.iref[2 * r]);
+        lane.st(R_YREF, j, 4, 0.0);   // "set steer rate to 0" (:271)
+    }
+    lane.st(R_YREFE, N, 0, tr.sref[3 * target]); lane.st(R_YREFE, N, 1, tr.sref[3 * target + 1]);
+    lane.st(R_YREFE, N, 2, tr.sref[3 * target + 2]);
+    lane.st(R_X0, N, 0, cx); lane.st(R_X0, N, 1, cy); lane.st(R_X0, N, 2, cpsi);
+}
+
+// After the solve: adopt u0 unless the solver failed (src/optimizer.cpp:290-296), then
+// Optimizer::integrate_next_states (:321-341).
+__global__ __launch_bounds__(MPC_WAVE) void k_track_advance(Consts c, Mem m, Track tr, int B) {
+    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
+    const unsigned l = threadIdx.x;
+    const size_t i = wbase + l;
+    if (i >= (size_t)B) return;
+    Lane lane(c, m, wbase, l);
+    double v = tr.u[2 * i], dl = tr.u[2 * i + 1];
+    if (m.STATUS[i] == 0) {
+        v = lane.ld(R_U0, c.N, 0); dl = lane.ld(R_U0, c.N, 1);
+        tr.u[2 * i] = v; tr.u[2 * i + 1] = dl;
+    }
+    double x0 = tr.x[3 * i], x1 = tr.x[3 * i + 1], psi = tr.x[3 * i + 2];
+    plant_step(c, x0, x1, psi, v, dl);
+    tr.x[3 * i] = x0; tr.x[3 * i + 1] = x1; tr.x[3 * i + 2] = psi;
 }
 
 // ------------------------------------------------------------------------------------
@@ -245,6 +337,10 @@ struct Shard {
     double *s_x0 = nullptr, *s_yref = nullptr, *s_yrefe = nullptr, *s_u0 = nullptr;
     double *s_xt = nullptr, *s_ut = nullptr, *s_pi = nullptr;
     unsigned char* s_mask = nullptr;
+    // closed-loop tracker (mpc_batch_track_*): path table and per-vehicle state
+    double *t_sref = nullptr, *t_iref = nullptr, *t_x = nullptr, *t_u = nullptr;
+    int* t_idx = nullptr;
+    int t_M = 0, t_Mi = 0;
 };
 
 struct mpc_batch {
@@ -253,6 +349,8 @@ struct mpc_batch {
     int capacity = 0;
     std::vector<Shard> shards;
     double last_ms = 0.0;
+    double t_density = 0.0;   // tracker parameters (mpc_batch_track_init)
+    int t_limit = 0;
     std::string err;
 };
 
@@ -272,6 +370,7 @@ static void free_shard(Shard& s) {
     (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
+    (void)hipFree(s.t_sref); (void)hipFree(s.t_iref); (void)hipFree(s.t_x); (void)hipFree(s.t_u); (void)hipFree(s.t_idx);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     for (hipEvent_t e : s.ev_ph) if (e) (void)hipEventDestroy(e);
@@ -280,6 +379,7 @@ static void free_shard(Shard& s) {
 }
 
 static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
+static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st);
 
 // Enqueue the device work of one solve on shard s for its first `n` instances; all pointers
 // are device pointers in the C-ABI's AoS layouts (any of the optional ones may be null).
@@ -294,6 +394,22 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
     if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
+    int rc = enqueue_core(h, s, n, st);
+    if (rc != 0) return rc;
+    if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
+    if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
+    if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
+    if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// The solve proper on inputs already in the workspace rows (R_X0, R_YREF, R_YREFE; iterate in
+// R_X, R_U): one RTI step, or the full SQP loop.
+static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
+    const int N = h->spec.N;
+    Mem& m = s.mem;
     const bool sqp = h->spec.sqp_max_iter > 1;
     const int iters = sqp ? h->spec.sqp_max_iter : 1;
     const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
@@ -343,11 +459,6 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
             s.n_ph = 1;
         }
     }
-    if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
-    if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
-    if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
-    if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
-    if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -626,6 +737,107 @@ double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
     }
     return h->last_ms;
 }
+// ---- closed loop on the device ------------------------------------------------------------
+static Track make_track(const mpc_batch* h, const Shard& s) {
+    Track tr;
+    tr.sref = s.t_sref; tr.iref = s.t_iref; tr.M = s.t_M; tr.Mi = s.t_Mi;
+    tr.x = s.t_x; tr.u = s.t_u; tr.idx = s.t_idx;
+    tr.density = h->t_density; tr.limit = h->t_limit; tr.lookahead = 1;
+    return tr;
+}
+
+int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, int Mi, const double* input_refs) {
+    if (!h || M < 1 || Mi < 1 || !state_refs || !input_refs) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        (void)hipFree(s.t_sref); (void)hipFree(s.t_iref);
+        s.t_sref = s.t_iref = nullptr;
+        HIPCHK(h, hipMalloc(&s.t_sref, sizeof(double) * 3 * M));
+        HIPCHK(h, hipMalloc(&s.t_iref, sizeof(double) * 2 * Mi));
+        HIPCHK(h, hipMemcpy(s.t_sref, state_refs, sizeof(double) * 3 * M, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(s.t_iref, input_refs, sizeof(double) * 2 * Mi, hipMemcpyHostToDevice));
+        s.t_M = M; s.t_Mi = Mi;
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, double v_ref) {
+    if (!h || B < 1 || B > h->capacity || !x_init || !(T > 0.0) || !(v_ref > 0.0)) return -1;
+    // Optimizer::Optimizer (src/optimizer.cpp:128, 174) and find_next_waypoint's statics (:387-391)
+    h->t_density = 1.0 / T / v_ref;
+    const double v_lim = v_ref > 0.3 ? 0.35 : v_ref;
+    h->t_limit = (int)floor(3.95 / (v_lim * T));
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        if (!s.t_sref) { h->err = "mpc_batch_track_init: call mpc_batch_track_set_path first"; (void)hipSetDevice(prev); return -1; }
+        HIPCHK(h, hipSetDevice(s.device));
+        if (!s.t_x) {
+            HIPCHK(h, hipMalloc(&s.t_x, sizeof(double) * 3 * s.S));
+            HIPCHK(h, hipMalloc(&s.t_u, sizeof(double) * 2 * s.S));
+            HIPCHK(h, hipMalloc(&s.t_idx, sizeof(int) * 4 * s.S));
+        }
+        HIPCHK(h, hipMemcpyAsync(s.t_x, x_init + 3 * (size_t)s.first, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemsetAsync(s.t_u, 0, sizeof(double) * 2 * s.S, s.stream));
+        HIPCHK(h, hipMemsetAsync(s.t_idx, 0, sizeof(int) * 4 * s.S, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u, int* target, int* status) {
+    if (!h || B < 1 || B > h->capacity || n_ticks < 0) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        if (!s.t_x) { h->err = "mpc_batch_track_run: call mpc_batch_track_init first"; (void)hipSetDevice(prev); return -1; }
+        HIPCHK(h, hipSetDevice(s.device));
+        const Track tr = make_track(h, s);
+        const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
+        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+        for (int t = 0; t < n_ticks; ++t) {
+            hipLaunchKernelGGL(k_track_select, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
+            int rc = enqueue_core(h, s, n, s.stream);
+            if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+            hipLaunchKernelGGL(k_track_advance, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
+        }
+        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+        HIPCHK(h, hipGetLastError());
+    }
+    double worst = 0.0;
+    std::vector<int> idx4;
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        const size_t o = (size_t)s.first;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess && ms > worst) worst = ms;
+        if (x) HIPCHK(h, hipMemcpy(x + 3 * o, s.t_x, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+        if (u) HIPCHK(h, hipMemcpy(u + 2 * o, s.t_u, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+        if (status) HIPCHK(h, hipMemcpy(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost));
+        if (target) {
+            idx4.resize(4 * (size_t)n);
+            HIPCHK(h, hipMemcpy(idx4.data(), s.t_idx, sizeof(int) * 4 * n, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) target[o + i] = idx4[4 * (size_t)i];
+        }
+    }
+    h->last_ms = worst;
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
 // Full SQP (sqp_max_iter > 1): per-instance number of QPs solved and the last NLP residuals
 // (stat, eq, ineq, comp) of the last solve.  Host pointers, either may be NULL.
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {

@@ -310,3 +310,39 @@ def test_full_sqp_matches_oracle(oracle, name, B):
     assert np.array_equal(ro2["status"][s2], rg2["status"][s2])
     assert np.abs(ro2["u0"] - rg2["u0"])[s2].max() < TOL_PATH
     solver.close()
+
+
+def test_device_closed_loop_matches_per_vehicle_optimizers(oracle):
+    """mpc_batch_track_* (window selection + reference packing + solve + plant step,
+    all on the device) against B independent host-side `Optimizer` mirrors running on the oracle:
+    same target waypoint on every tick, commands and states within the parity bar."""
+    import os
+    from mpc_amd.optimizer import Optimizer, load_txt
+    from tests.oracle_solver import OracleSolver
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))
+    u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))
+    B, T, v_ref = 40, 0.1, 0.5
+    rng = np.random.Generator(np.random.PCG64(11))
+    start = s[rng.integers(0, 60, B)] + rng.normal(0, 1, (B, 3)) * np.array([0.05, 0.05, 0.1])
+    start[0] = s[0] + np.array([1.5, 0.3, 0.0])      # > 1.2 m from the path: window-widening branch
+    opts = [Optimizer(T, 40, v_ref, *start[i], state_refs=s, input_refs=u, solver_factory=OracleSolver) for i in range(B)]
+    solver = capi.BatchSolver(opts[0].spec, B)
+    solver.track_set_path(s, u)
+    solver.track_init(start, T, v_ref)
+    for k in range(30):
+        r = solver.track_run(1)
+        for i, o in enumerate(opts):
+            rc = o.update_and_solve(o.x_current)
+            o.integrate_next_states()
+            assert (rc == 0) == (r["status"][i] == 0)
+            assert o.target_waypoint_index == r["target"][i], (k, i)
+        uo = np.array([o.u_current for o in opts]); xo = np.array([o.x_current for o in opts])
+        assert np.abs(uo - r["u"]).max() < TOL_HARD and np.abs(xo - r["x"]).max() < TOL_HARD, k
+    # several ticks per call = the same as tick by tick
+    solver2 = capi.BatchSolver(opts[0].spec, B)
+    solver2.track_set_path(s, u)
+    solver2.track_init(start, T, v_ref)
+    r2 = solver2.track_run(30)
+    assert np.array_equal(r2["target"], r["target"]) and np.abs(r2["x"] - r["x"]).max() < 1e-12
+    solver.close(); solver2.close()
