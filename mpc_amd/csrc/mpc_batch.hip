@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "consts.hpp"
+#include "rti_wave.hpp"
 
 using namespace mpc;
 
@@ -71,6 +72,66 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
         else lane.finish(s, home);
     }
     if (flags && inrange) flags[wbase + l] = go ? 1 : 0;
+}
+
+// The whole SQP-RTI step with one OCP per GW-lane group (GW = 64: one per wavefront), lane =
+// stage, workspace in registers (rti_wave.hpp).  Reads the iterate and the references from the
+// instance's workspace column and writes the new iterate, u0, status back to it; nothing else
+// touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
+// the full wave); a group whose instance has converged is masked by `go`.
+template <int GW>
+__global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
+    constexpr int G = MPC_WAVE / GW;
+    const int l = threadIdx.x;
+    const int g = l / GW, k = l % GW;
+    const size_t i = (size_t)blockIdx.x * G + g;
+    const int N = c.N;
+    const bool inst = i < (size_t)B;
+    const size_t ic = inst ? i : (size_t)B - 1;
+    const int kcl = k <= N ? k : N;
+    double* col = reinterpret_cast<double*>(m.slab + (ic >> 6) * m.wave_bytes) + (ic & 63);
+    double* sk = col + ((size_t)(kcl * MPC_RPS) << 6);
+    double* sN = col + ((size_t)(N * MPC_RPS) << 6);
+    Wave<GW> w(c, k);
+    const bool on = inst && k <= N;
+    double xi[3], ui[2], x0b[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) xi[q] = on ? sk[(R_X + q) << 6] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ui[q] = (on && k < N) ? sk[(R_U + q) << 6] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? sN[(R_X0 + q) << 6] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
+    w.prepare(xi, ui, x0b);
+    typename Wave<GW>::State s;
+    w.begin(s);
+    for (;;) {
+        const bool go = inst && w.cont(s);
+        if (!__any(go)) break;
+        if (go) w.iterate(s);
+    }
+    // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping), full-step update
+    int hs;
+    if (s.kk == c.iter_max) hs = 1;
+    else if (s.alpha <= c.alpha_min) hs = 2;
+    else if (s.mu != s.mu) hs = 3;
+    else hs = 0;
+    const bool ok = (hs == 0 || hs == 1);
+    if (!on) return;
+    if (k == 0) { m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = ok ? 0 : 4; }
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = w.z[2 + q];
+        if (k < N) {
+            sk[(R_U + 0) << 6] = w.z[0]; sk[(R_U + 1) << 6] = w.z[1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = w.pi[q];
+        }
+        if (k == 0) { sN[(R_U0 + 0) << 6] = w.z[0]; sN[(R_U0 + 1) << 6] = w.z[1]; }
+    } else if (k == 0) {
+        sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];   // previous u_0 stays in force
+    }
 }
 
 // Full SQP only (spec.sqp_max_iter > 1; BASELINE config 5): the head of one SQP iteration.
@@ -414,6 +475,21 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     const int iters = sqp ? h->spec.sqp_max_iter : 1;
     const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
     s.sqp_rounds = 0;
+    // Execution model.  MPC_MODEL=lane forces the one-OCP-per-lane kernels (k_phase), =wave the
+    // one-OCP-per-wavefront kernel (k_wave; needs N + 1 <= 64 and plain RTI).
+    static const char* model_env = getenv("MPC_MODEL");
+    const bool wave_ok = !sqp && N + 1 <= MPC_WAVE;
+    const bool use_wave = wave_ok && !(model_env && strcmp(model_env, "lane") == 0);
+    if (use_wave) {
+        HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+        if (N + 1 <= 16) hipLaunchKernelGGL(k_wave<16>, dim3((n + 3) / 4), dim3(MPC_WAVE), 0, st, h->consts, m, n);
+        else if (N + 1 <= 32) hipLaunchKernelGGL(k_wave<32>, dim3((n + 1) / 2), dim3(MPC_WAVE), 0, st, h->consts, m, n);
+        else hipLaunchKernelGGL(k_wave<64>, dim3(n), dim3(MPC_WAVE), 0, st, h->consts, m, n);
+        HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
+        s.n_ph = 1;
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     for (int it = 0; it < iters; ++it) {
         if (sqp) {
             // head of an SQP iteration; the host reads the number of instances still iterating

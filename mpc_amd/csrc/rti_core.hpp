@@ -95,48 +95,21 @@ struct Mem {
 #define MPC_DIAG_LQ 2     /* HPIPM's lq_fact=1 test would have switched to the LQ factorisation */
 
 // ------------------------------------------------------------------------------------
-struct Lane {
+// Per-stage algebra shared by the two execution models (one OCP per lane: Lane below; one OCP
+// per wavefront: rti_wave.hpp).  No memory access in here.
+struct Algebra {
     const Consts& c;
-    const Mem& m;
-    size_t wbase;   // first instance of this wavefront (wave-uniform)
-    unsigned lane;  // threadIdx.x
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff;
-    __device__ __forceinline__ Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
-        : c(c_), m(m_), wbase(wbase_), lane(lane_) {
-        char* blk = m.slab + (wbase >> 6) * m.wave_bytes;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)m.wave_bytes, 0x00020000);
-        voff = lane_ * 8u;
-    }
-    __device__ __forceinline__ double ld(int field, int k, int comp) const {
-        // rows are split 8 + 3 bits: the low part folds into the instruction's 12-bit immediate
-        // offset, so one scalar offset serves 8 rows
-        const int row = field + comp;
-        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + ((unsigned)(row & 7) << 9), so, 0));
-    }
-    __device__ __forceinline__ void st(int field, int k, int comp, double v) const {
-        const int row = field + comp;
-        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, voff + ((unsigned)(row & 7) << 9), so, 0);
-    }
-#else
-    double* blk;
-    MPC_HD Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
-        : c(c_), m(m_), wbase(wbase_), lane(lane_) {
-        blk = reinterpret_cast<double*>(m.slab + (wbase >> 6) * m.wave_bytes) + lane_;
-    }
-    MPC_HD double ld(int field, int k, int comp) const { return blk[(size_t)(k * MPC_RPS + field + comp) << 6]; }
-    MPC_HD void st(int field, int k, int comp, double v) const { blk[(size_t)(k * MPC_RPS + field + comp) << 6] = v; }
-#endif
+    MPC_HD explicit Algebra(const Consts& c_) : c(c_) {}
+
+    // ---- small value types (kept in registers) ----
+    struct AB8 { double a, b, B00, B10, B20, B01, B11, B21; };
+    struct Sym3 { double p00, p10, p11, p20, p21, p22; };
+    struct Bnd { double lam[8], t[8]; };  // [0..3] lower, [4..7] upper of (v, delta, x, y)
 
     // ---- H5/H7: ERK4 with forward sensitivities, structure-exploiting but with the generic
     //      integrator's operation order (entries that are structurally 0/1 are exact there too)
-    MPC_HD void linearize_stage(int k, double* xn_out = nullptr) const {
-        const double x0 = ld(R_X, k, 0), x1 = ld(R_X, k, 1), psi = ld(R_X, k, 2);
-        const double v = ld(R_U, k, 0), dl = ld(R_U, k, 1);
+    MPC_HD void linearize_math(double x0, double x1, double psi, double v, double dl, AB8& ab, double cv[3],
+                               double xn[3]) const {
         const double h = c.Ts;
         const double tg = tan(dl), cd = cos(dl);
         const double vL = v / c.L;
@@ -181,97 +154,12 @@ struct Lane {
         const double B01 = (((0.0 + bw0 * k1B01) + bw1 * k2B01) + bw1 * k2B01) + bw0 * k4B01;
         const double B11 = (((0.0 + bw0 * k1B11) + bw1 * k2B11) + bw1 * k2B11) + bw0 * k4B11;
         const double B21 = (((0.0 + bw0 * s21) + bw1 * s21) + bw1 * s21) + bw0 * s21;
-        st(R_AB, k, 0, a);   st(R_AB, k, 1, b);
-        st(R_AB, k, 2, B00); st(R_AB, k, 3, B10); st(R_AB, k, 4, B20);
-        st(R_AB, k, 5, B01); st(R_AB, k, 6, B11); st(R_AB, k, 7, B21);
+        ab.a = a; ab.b = b; ab.B00 = B00; ab.B10 = B10; ab.B20 = B20; ab.B01 = B01; ab.B11 = B11; ab.B21 = B21;
         // affine term of the absolute formulation: zeta_x+ = A zeta_x + B zeta_u + cvec
-        st(R_C, k, 0, xn0 - (x0 + a * psi) - (B00 * v + B01 * dl));
-        st(R_C, k, 1, xn1 - (x1 + b * psi) - (B10 * v + B11 * dl));
-        st(R_C, k, 2, xn2 - psi - (B20 * v + B21 * dl));
-        if (xn_out) { xn_out[0] = xn0; xn_out[1] = xn1; xn_out[2] = xn2; }
-    }
-
-    // ---- full SQP only (BASELINE config 5; acados ocp_nlp_sqp.c / ocp_nlp_res_compute restated,
-    //      no counterpart in the reference's SQP_RTI solvers): linearise every stage at the
-    //      iterate and evaluate the NLP residuals with the multipliers of the last QP:
-    //      out = { ||cost_grad + dyn_adj + ineq_adj||_inf (stage-0 state rows excluded),
-    //              ||phi(x_k,u_k) - x_{k+1}||_inf, max(0, lb - z, z - ub, |x_0 - x0bar|),
-    //              max |lam_j * violation_j| }.
-    MPC_HD void nlp_res_and_linearize(double out[4]) const {
-        const int N = uniform(c.N);
-        double r_stat = 0.0, r_eq = 0.0, r_ineq = 0.0, r_comp = 0.0;
-        for (int i = 0; i < 3; ++i) r_ineq = amax(r_ineq, ld(R_X0, N, i) - ld(R_X, 0, i));
-        double pim0 = 0.0, pim1 = 0.0, pim2 = 0.0;
-        for (int k = 0; k <= N; ++k) {
-            double z[5], g[5];
-            z[0] = (k < N) ? ld(R_U, k, 0) : 0.0;
-            z[1] = (k < N) ? ld(R_U, k, 1) : 0.0;
-            z[2] = ld(R_X, k, 0); z[3] = ld(R_X, k, 1); z[4] = ld(R_X, k, 2);
-            if (k < N) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) g[i] = c.wg[i] * (z[i] - ld(R_YREF, k, i < 2 ? 3 + i : i - 2));
-            } else {
-                g[0] = g[1] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) g[2 + i] = c.we[i] * (z[2 + i] - ld(R_YREFE, N, i));
-            }
-            if (k > 0) { g[2] -= pim0; g[3] -= pim1; g[4] -= pim2; }
-            if (k < N) {
-                const int nb = (k == 0) ? 2 : 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < nb) {
-                        const double dl = c.lb[j] - z[j], du = z[j] - c.ub[j];
-                        const double ll = ld(R_LAM, k, j), lu = ld(R_LAM, k, 4 + j);
-                        g[j] += lu - ll;
-                        r_ineq = fmax(r_ineq, dl); r_ineq = fmax(r_ineq, du);
-                        r_comp = amax(r_comp, ll * dl); r_comp = amax(r_comp, lu * du);
-                    }
-                }
-                double xn[3];
-                linearize_stage(k, xn);
-                const AB8 ab = ld_ab(k);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) r_eq = amax(r_eq, xn[j] - ld(R_X, k + 1, j));
-                const double p0 = ld(R_PI, k, 0), p1 = ld(R_PI, k, 1), p2 = ld(R_PI, k, 2);
-                g[0] += ab.B00 * p0 + ab.B10 * p1 + ab.B20 * p2;
-                g[1] += ab.B01 * p0 + ab.B11 * p1 + ab.B21 * p2;
-                g[2] += p0; g[3] += p1; g[4] += ab.a * p0 + ab.b * p1 + p2;
-                pim0 = p0; pim1 = p1; pim2 = p2;
-            }
-            if (k < N) { r_stat = amax(r_stat, g[0]); r_stat = amax(r_stat, g[1]); }
-            if (k > 0) { r_stat = amax(r_stat, g[2]); r_stat = amax(r_stat, g[3]); r_stat = amax(r_stat, g[4]); }
-        }
-        out[0] = r_stat; out[1] = r_eq; out[2] = r_ineq; out[3] = r_comp;
-    }
-
-    // ---- small value types (kept in registers) ----
-    struct AB8 { double a, b, B00, B10, B20, B01, B11, B21; };
-    struct Sym3 { double p00, p10, p11, p20, p21, p22; };
-    struct Bnd { double lam[8], t[8]; };  // [0..3] lower, [4..7] upper of (v, delta, x, y)
-
-    MPC_HD AB8 ld_ab(int k) const {
-        AB8 r;
-        r.a = ld(R_AB, k, 0); r.b = ld(R_AB, k, 1);
-        r.B00 = ld(R_AB, k, 2); r.B10 = ld(R_AB, k, 3); r.B20 = ld(R_AB, k, 4);
-        r.B01 = ld(R_AB, k, 5); r.B11 = ld(R_AB, k, 6); r.B21 = ld(R_AB, k, 7);
-        return r;
-    }
-    MPC_HD Sym3 ld_P(int k) const {
-        Sym3 r;
-        r.p00 = ld(R_P, k, 0); r.p10 = ld(R_P, k, 1); r.p11 = ld(R_P, k, 2);
-        r.p20 = ld(R_P, k, 3); r.p21 = ld(R_P, k, 4); r.p22 = ld(R_P, k, 5);
-        return r;
-    }
-    MPC_HD void st_P(int k, const Sym3& P) const {
-        st(R_P, k, 0, P.p00); st(R_P, k, 1, P.p10); st(R_P, k, 2, P.p11);
-        st(R_P, k, 3, P.p20); st(R_P, k, 4, P.p21); st(R_P, k, 5, P.p22);
-    }
-    MPC_HD Bnd ld_bnd(int k) const {
-        Bnd r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { r.lam[j] = ld(R_LAM, k, j); r.t[j] = ld(R_T, k, j); }
-        return r;
+        cv[0] = xn0 - (x0 + a * psi) - (B00 * v + B01 * dl);
+        cv[1] = xn1 - (x1 + b * psi) - (B10 * v + B11 * dl);
+        cv[2] = xn2 - psi - (B20 * v + B21 * dl);
+        xn[0] = xn0; xn[1] = xn1; xn[2] = xn2;
     }
 
     // Stage indices are the same in every lane, but after control-flow restructuring the
@@ -381,6 +269,135 @@ struct Lane {
             solve2(g.id0, g.l10, g.id1, g.M01, g.M11, g.K01, g.K11);
             solve2(g.id0, g.l10, g.id1, g.X02, g.X12, g.K02, g.K12);
         }
+    }
+
+};
+
+// ------------------------------------------------------------------------------------
+struct Lane : Algebra {
+    const Mem& m;
+    size_t wbase;   // first instance of this wavefront (wave-uniform)
+    unsigned lane;  // threadIdx.x
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff;
+    __device__ __forceinline__ Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
+        : Algebra(c_), m(m_), wbase(wbase_), lane(lane_) {
+        char* blk = m.slab + (wbase >> 6) * m.wave_bytes;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)m.wave_bytes, 0x00020000);
+        voff = lane_ * 8u;
+    }
+    __device__ __forceinline__ double ld(int field, int k, int comp) const {
+        // rows are split 8 + 3 bits: the low part folds into the instruction's 12-bit immediate
+        // offset, so one scalar offset serves 8 rows
+        const int row = field + comp;
+        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + ((unsigned)(row & 7) << 9), so, 0));
+    }
+    __device__ __forceinline__ void st(int field, int k, int comp, double v) const {
+        const int row = field + comp;
+        const unsigned so = (unsigned)(k * MPC_RPS + (row & ~7)) << 9;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, voff + ((unsigned)(row & 7) << 9), so, 0);
+    }
+#else
+    double* blk;
+    MPC_HD Lane(const Consts& c_, const Mem& m_, size_t wbase_, unsigned lane_)
+        : Algebra(c_), m(m_), wbase(wbase_), lane(lane_) {
+        blk = reinterpret_cast<double*>(m.slab + (wbase >> 6) * m.wave_bytes) + lane_;
+    }
+    MPC_HD double ld(int field, int k, int comp) const { return blk[(size_t)(k * MPC_RPS + field + comp) << 6]; }
+    MPC_HD void st(int field, int k, int comp, double v) const { blk[(size_t)(k * MPC_RPS + field + comp) << 6] = v; }
+#endif
+
+    // ---- H5/H7 on the workspace rows of stage k
+    MPC_HD void linearize_stage(int k, double* xn_out = nullptr) const {
+        AB8 ab;
+        double cv[3], xn[3];
+        linearize_math(ld(R_X, k, 0), ld(R_X, k, 1), ld(R_X, k, 2), ld(R_U, k, 0), ld(R_U, k, 1), ab, cv, xn);
+        st(R_AB, k, 0, ab.a);   st(R_AB, k, 1, ab.b);
+        st(R_AB, k, 2, ab.B00); st(R_AB, k, 3, ab.B10); st(R_AB, k, 4, ab.B20);
+        st(R_AB, k, 5, ab.B01); st(R_AB, k, 6, ab.B11); st(R_AB, k, 7, ab.B21);
+        st(R_C, k, 0, cv[0]); st(R_C, k, 1, cv[1]); st(R_C, k, 2, cv[2]);
+        if (xn_out) { xn_out[0] = xn[0]; xn_out[1] = xn[1]; xn_out[2] = xn[2]; }
+    }
+
+    // ---- full SQP only (BASELINE config 5; acados ocp_nlp_sqp.c / ocp_nlp_res_compute restated,
+    //      no counterpart in the reference's SQP_RTI solvers): linearise every stage at the
+    //      iterate and evaluate the NLP residuals with the multipliers of the last QP:
+    //      out = { ||cost_grad + dyn_adj + ineq_adj||_inf (stage-0 state rows excluded),
+    //              ||phi(x_k,u_k) - x_{k+1}||_inf, max(0, lb - z, z - ub, |x_0 - x0bar|),
+    //              max |lam_j * violation_j| }.
+    MPC_HD void nlp_res_and_linearize(double out[4]) const {
+        const int N = uniform(c.N);
+        double r_stat = 0.0, r_eq = 0.0, r_ineq = 0.0, r_comp = 0.0;
+        for (int i = 0; i < 3; ++i) r_ineq = amax(r_ineq, ld(R_X0, N, i) - ld(R_X, 0, i));
+        double pim0 = 0.0, pim1 = 0.0, pim2 = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            double z[5], g[5];
+            z[0] = (k < N) ? ld(R_U, k, 0) : 0.0;
+            z[1] = (k < N) ? ld(R_U, k, 1) : 0.0;
+            z[2] = ld(R_X, k, 0); z[3] = ld(R_X, k, 1); z[4] = ld(R_X, k, 2);
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) g[i] = c.wg[i] * (z[i] - ld(R_YREF, k, i < 2 ? 3 + i : i - 2));
+            } else {
+                g[0] = g[1] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) g[2 + i] = c.we[i] * (z[2 + i] - ld(R_YREFE, N, i));
+            }
+            if (k > 0) { g[2] -= pim0; g[3] -= pim1; g[4] -= pim2; }
+            if (k < N) {
+                const int nb = (k == 0) ? 2 : 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nb) {
+                        const double dl = c.lb[j] - z[j], du = z[j] - c.ub[j];
+                        const double ll = ld(R_LAM, k, j), lu = ld(R_LAM, k, 4 + j);
+                        g[j] += lu - ll;
+                        r_ineq = fmax(r_ineq, dl); r_ineq = fmax(r_ineq, du);
+                        r_comp = amax(r_comp, ll * dl); r_comp = amax(r_comp, lu * du);
+                    }
+                }
+                double xn[3];
+                linearize_stage(k, xn);
+                const AB8 ab = ld_ab(k);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r_eq = amax(r_eq, xn[j] - ld(R_X, k + 1, j));
+                const double p0 = ld(R_PI, k, 0), p1 = ld(R_PI, k, 1), p2 = ld(R_PI, k, 2);
+                g[0] += ab.B00 * p0 + ab.B10 * p1 + ab.B20 * p2;
+                g[1] += ab.B01 * p0 + ab.B11 * p1 + ab.B21 * p2;
+                g[2] += p0; g[3] += p1; g[4] += ab.a * p0 + ab.b * p1 + p2;
+                pim0 = p0; pim1 = p1; pim2 = p2;
+            }
+            if (k < N) { r_stat = amax(r_stat, g[0]); r_stat = amax(r_stat, g[1]); }
+            if (k > 0) { r_stat = amax(r_stat, g[2]); r_stat = amax(r_stat, g[3]); r_stat = amax(r_stat, g[4]); }
+        }
+        out[0] = r_stat; out[1] = r_eq; out[2] = r_ineq; out[3] = r_comp;
+    }
+
+    MPC_HD AB8 ld_ab(int k) const {
+        AB8 r;
+        r.a = ld(R_AB, k, 0); r.b = ld(R_AB, k, 1);
+        r.B00 = ld(R_AB, k, 2); r.B10 = ld(R_AB, k, 3); r.B20 = ld(R_AB, k, 4);
+        r.B01 = ld(R_AB, k, 5); r.B11 = ld(R_AB, k, 6); r.B21 = ld(R_AB, k, 7);
+        return r;
+    }
+    MPC_HD Sym3 ld_P(int k) const {
+        Sym3 r;
+        r.p00 = ld(R_P, k, 0); r.p10 = ld(R_P, k, 1); r.p11 = ld(R_P, k, 2);
+        r.p20 = ld(R_P, k, 3); r.p21 = ld(R_P, k, 4); r.p22 = ld(R_P, k, 5);
+        return r;
+    }
+    MPC_HD void st_P(int k, const Sym3& P) const {
+        st(R_P, k, 0, P.p00); st(R_P, k, 1, P.p10); st(R_P, k, 2, P.p11);
+        st(R_P, k, 3, P.p20); st(R_P, k, 4, P.p21); st(R_P, k, 5, P.p22);
+    }
+    MPC_HD Bnd ld_bnd(int k) const {
+        Bnd r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r.lam[j] = ld(R_LAM, k, j); r.t[j] = ld(R_T, k, j); }
+        return r;
     }
 
     // ---- preparation sweep (forward): ERK4 linearisation + OCP_QP_INIT_VAR cold start ----
