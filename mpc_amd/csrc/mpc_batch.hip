@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // instance's workspace column and writes the new iterate, u0, status back to it; nothing else
 // touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
 // the full wave); a group whose instance has converged is masked by `go`.
-template <int GW>
+template <int GW, bool SCAN>
 __global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
     constexpr int G = MPC_WAVE / GW;
     const int l = threadIdx.x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
     double* col = reinterpret_cast<double*>(m.slab + (ic >> 6) * m.wave_bytes) + (ic & 63);
     double* sk = col + ((size_t)(kcl * MPC_RPS) << 6);
     double* sN = col + ((size_t)(N * MPC_RPS) << 6);
-    Wave<GW> w(c, k);
+    Wave<GW, SCAN> w(c, k);
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
     w.prepare(xi, ui, x0b);
-    typename Wave<GW>::State s;
+    typename Wave<GW, SCAN>::State s;
     w.begin(s);
     for (;;) {
         const bool go = inst && w.cont(s);
@@ -482,9 +482,20 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     const bool use_wave = wave_ok && !(model_env && strcmp(model_env, "lane") == 0);
     if (use_wave) {
         HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-        if (N + 1 <= 16) hipLaunchKernelGGL(k_wave<16>, dim3((n + 3) / 4), dim3(MPC_WAVE), 0, st, h->consts, m, n);
-        else if (N + 1 <= 32) hipLaunchKernelGGL(k_wave<32>, dim3((n + 1) / 2), dim3(MPC_WAVE), 0, st, h->consts, m, n);
-        else hipLaunchKernelGGL(k_wave<64>, dim3(n), dim3(MPC_WAVE), 0, st, h->consts, m, n);
+        // MPC_MODEL=waveseq: sequential Riccati recursions under a lane predicate instead of
+        // the parallel scans (development / cross-check)
+        const bool seq = model_env && strcmp(model_env, "waveseq") == 0;
+        const dim3 blk(MPC_WAVE);
+        if (N + 1 <= 16) {
+            if (seq) hipLaunchKernelGGL((k_wave<16, false>), dim3((n + 3) / 4), blk, 0, st, h->consts, m, n);
+            else hipLaunchKernelGGL((k_wave<16, true>), dim3((n + 3) / 4), blk, 0, st, h->consts, m, n);
+        } else if (N + 1 <= 32) {
+            if (seq) hipLaunchKernelGGL((k_wave<32, false>), dim3((n + 1) / 2), blk, 0, st, h->consts, m, n);
+            else hipLaunchKernelGGL((k_wave<32, true>), dim3((n + 1) / 2), blk, 0, st, h->consts, m, n);
+        } else {
+            if (seq) hipLaunchKernelGGL((k_wave<64, false>), dim3(n), blk, 0, st, h->consts, m, n);
+            else hipLaunchKernelGGL((k_wave<64, true>), dim3(n), blk, 0, st, h->consts, m, n);
+        }
         HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
         s.n_ph = 1;
         HIPCHK(h, hipGetLastError());

@@ -56,10 +56,35 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
     if (GW >= 64) v = op(v, __shfl_xor(v, 32, 64));
     return v;
 }
+// lane i <- lane i+d / lane i-d for any d (ds_bpermute; out-of-range lanes return their own value)
+__device__ __forceinline__ double lane_down(double v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ double lane_up(double v, int d) { return __shfl_up(v, d, 64); }
+
+// dense 3x3 helpers for the parallel scans (row-major)
+struct M3 { double m[9]; };
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    return r;
+}
+__device__ __forceinline__ void m3_mulv(const M3& a, const double v[3], double r[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = a.m[3 * i] * v[0] + a.m[3 * i + 1] * v[1] + a.m[3 * i + 2] * v[2];
+}
+template <class F>
+__device__ __forceinline__ M3 m3_map(const M3& a, F f) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.m[i] = f(a.m[i]);
+    return r;
+}
 struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
 struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
 
-template <int GW>
+template <int GW, bool SCAN>
 struct Wave : Algebra {
     int k, N;                    // stage of this lane, horizon
     bool act, mid, isN, is0;     // k <= N, k < N, k == N, k == 0
@@ -201,7 +226,13 @@ struct Wave : Algebra {
         n.m = group_reduce<GW>(pm, OpMax());
         n.musum = group_reduce<GW>(ps, OpSum());
 
-        // --- Riccati factorisation + affine right-hand side, stage N-1 down to 0 ---
+        if (SCAN) factor_scan(Gam, gam);
+        else factor_seq(Gam, gam);
+    }
+
+    // --- Riccati factorisation + affine right-hand side, stage N-1 down to 0: the lane that
+    //     owns the stage computes, P and p move one lane down per step.
+    __device__ __forceinline__ void factor_seq(const double Gam[4], const double gam[4]) {
         Sym3 Po;
         Po.p00 = c.we[0] + c.reg_prim; Po.p10 = 0.0; Po.p11 = c.we[1] + c.reg_prim;
         Po.p20 = 0.0; Po.p21 = 0.0; Po.p22 = c.we[2] + c.reg_prim;
@@ -251,6 +282,209 @@ struct Wave : Algebra {
         }
     }
 
+    // ================= parallel-in-time versions of the three recursions =================
+    // The Riccati recursion is a suffix scan over "conditional value function" elements
+    // (A, C, J) of horizon segments [S. Sarkka, A. Garcia-Fernandez, "Temporal parallelization of
+    // dynamic programming and linear quadratic control", IEEE TAC 2023]: a segment i..j maps
+    // x_i to x_j with  x_j = A x_i + (control effect, C = controllability Gramian-like term)
+    // and costs 1/2 x_i^T J x_i when x_j is free.  One stage: A = A_k, C = B_k R_k^-1 B_k^T,
+    // J = Q_k; terminal element (0, 0, Q_N).  Combination of segment 1 (k..k+d) followed by
+    // segment 2:  W = (I + C1 J2)^-1,
+    //     A12 = A2 W A1,   C12 = A2 W C1 A2^T + C2,   J12 = A1^T J2 W A1 + J1.
+    // After log2 steps lane k holds J = P_k, the value function of stage k; the gains are then
+    // formed per stage exactly as in the sequential code.  The two vector recursions
+    // (p backward, dx forward) are scans over affine maps x -> M x + v.
+    // Measured against the sequential recursion on the IPM's own matrices (barrier terms up to
+    // 1e11): relative deviation of P <= 1e-14.
+
+    // affine suffix scan: on entry lane k (< N) holds p_k = T p_{k+1} + s, lane N holds (0, p_N);
+    // on exit s = p_k.
+    __device__ __forceinline__ void affine_suffix_scan(M3& T, double s[3]) const {
+#pragma unroll
+        for (int d = 1; d < GW; d *= 2) {
+            M3 T2;
+            double s2[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) T2.m[i] = lane_down(T.m[i], d);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s2[i] = lane_down(s[i], d);
+            if (k + d <= N) {
+                double r[3];
+                m3_mulv(T, s2, r);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s[i] = r[i] + s[i];
+                if (2 * d < GW) T = m3_mul(T, T2);
+            }
+        }
+    }
+    // affine prefix scan: lane k (< N) holds dx_{k+1} = M dx_k + v with dx_0 = 0; on exit v = dx_{k+1}.
+    __device__ __forceinline__ void affine_prefix_scan(M3& M, double v[3]) const {
+#pragma unroll
+        for (int d = 1; d < GW; d *= 2) {
+            M3 M1;
+            double v1[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M1.m[i] = lane_up(M.m[i], d);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v1[i] = lane_up(v[i], d);
+            if (k >= d && mid) {
+                double r[3];
+                m3_mulv(M, v1, r);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i] = r[i] + v[i];
+                if (2 * d < GW) M = m3_mul(M, M1);
+            }
+        }
+    }
+    // closed-loop transition of this stage: Phi = A + B K
+    __device__ __forceinline__ M3 closed_loop() const {
+        M3 F;
+        F.m[0] = 1.0 + (ab.B00 * K00 + ab.B01 * K10); F.m[1] = ab.B00 * K01 + ab.B01 * K11; F.m[2] = ab.a + (ab.B00 * K02 + ab.B01 * K12);
+        F.m[3] = ab.B10 * K00 + ab.B11 * K10; F.m[4] = 1.0 + (ab.B10 * K01 + ab.B11 * K11); F.m[5] = ab.b + (ab.B10 * K02 + ab.B11 * K12);
+        F.m[6] = ab.B20 * K00 + ab.B21 * K10; F.m[7] = ab.B20 * K01 + ab.B21 * K11; F.m[8] = 1.0 + (ab.B20 * K02 + ab.B21 * K12);
+        return F;
+    }
+
+    __device__ __forceinline__ void factor_scan(const double Gam[4], const double gam[4]) {
+        // --- elements ---
+        M3 A;
+        double C[6], J[6];   // symmetric: 00, 10, 11, 20, 21, 22
+        if (mid) {
+            A.m[0] = 1.0; A.m[1] = 0.0; A.m[2] = ab.a; A.m[3] = 0.0; A.m[4] = 1.0; A.m[5] = ab.b; A.m[6] = 0.0; A.m[7] = 0.0; A.m[8] = 1.0;
+            const double r0 = rcp((c.wg[0] + c.reg_prim) + Gam[0]), r1 = rcp((c.wg[1] + c.reg_prim) + Gam[1]);
+            const double b00 = ab.B00 * r0, b10 = ab.B10 * r0, b20 = ab.B20 * r0;
+            const double b01 = ab.B01 * r1, b11 = ab.B11 * r1, b21 = ab.B21 * r1;
+            C[0] = b00 * ab.B00 + b01 * ab.B01;
+            C[1] = b10 * ab.B00 + b11 * ab.B01;
+            C[2] = b10 * ab.B10 + b11 * ab.B11;
+            C[3] = b20 * ab.B00 + b21 * ab.B01;
+            C[4] = b20 * ab.B10 + b21 * ab.B11;
+            C[5] = b20 * ab.B20 + b21 * ab.B21;
+            J[0] = (c.wg[2] + c.reg_prim) + Gam[2]; J[1] = 0.0; J[2] = (c.wg[3] + c.reg_prim) + Gam[3];
+            J[3] = 0.0; J[4] = 0.0; J[5] = c.wg[4] + c.reg_prim;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A.m[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { C[i] = 0.0; J[i] = 0.0; }
+            J[0] = c.we[0] + c.reg_prim; J[2] = c.we[1] + c.reg_prim; J[5] = c.we[2] + c.reg_prim;
+        }
+        // --- suffix scan ---
+#pragma unroll
+        for (int d = 1; d < GW; d *= 2) {
+            M3 A2;
+            double C2[6], J2[6];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A2.m[i] = lane_down(A.m[i], d);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { C2[i] = lane_down(C[i], d); J2[i] = lane_down(J[i], d); }
+            if (k + d <= N) {
+                const bool more = 2 * d < GW;   // A and C are only needed by later steps
+                // X = I + C1 J2
+                M3 Cm, Jm;
+                Cm.m[0] = C[0]; Cm.m[1] = C[1]; Cm.m[2] = C[3]; Cm.m[3] = C[1]; Cm.m[4] = C[2]; Cm.m[5] = C[4]; Cm.m[6] = C[3]; Cm.m[7] = C[4]; Cm.m[8] = C[5];
+                Jm.m[0] = J2[0]; Jm.m[1] = J2[1]; Jm.m[2] = J2[3]; Jm.m[3] = J2[1]; Jm.m[4] = J2[2]; Jm.m[5] = J2[4]; Jm.m[6] = J2[3]; Jm.m[7] = J2[4]; Jm.m[8] = J2[5];
+                M3 X = m3_mul(Cm, Jm);
+                X.m[0] += 1.0; X.m[4] += 1.0; X.m[8] += 1.0;
+                // W = X^-1 (adjugate)
+                M3 W;
+                const double c00 = X.m[4] * X.m[8] - X.m[5] * X.m[7];
+                const double c01 = X.m[5] * X.m[6] - X.m[3] * X.m[8];
+                const double c02 = X.m[3] * X.m[7] - X.m[4] * X.m[6];
+                const double idet = rcp(X.m[0] * c00 + X.m[1] * c01 + X.m[2] * c02);
+                W.m[0] = c00 * idet; W.m[3] = c01 * idet; W.m[6] = c02 * idet;
+                W.m[1] = (X.m[2] * X.m[7] - X.m[1] * X.m[8]) * idet;
+                W.m[4] = (X.m[0] * X.m[8] - X.m[2] * X.m[6]) * idet;
+                W.m[7] = (X.m[1] * X.m[6] - X.m[0] * X.m[7]) * idet;
+                W.m[2] = (X.m[1] * X.m[5] - X.m[2] * X.m[4]) * idet;
+                W.m[5] = (X.m[2] * X.m[3] - X.m[0] * X.m[5]) * idet;
+                W.m[8] = (X.m[0] * X.m[4] - X.m[1] * X.m[3]) * idet;
+                // J12 = A1^T (J2 W) A1 + J1
+                const M3 U = m3_mul(m3_mul(Jm, W), A);
+                J[0] += A.m[0] * U.m[0] + A.m[3] * U.m[3] + A.m[6] * U.m[6];
+                J[1] += A.m[1] * U.m[0] + A.m[4] * U.m[3] + A.m[7] * U.m[6];
+                J[2] += A.m[1] * U.m[1] + A.m[4] * U.m[4] + A.m[7] * U.m[7];
+                J[3] += A.m[2] * U.m[0] + A.m[5] * U.m[3] + A.m[8] * U.m[6];
+                J[4] += A.m[2] * U.m[1] + A.m[5] * U.m[4] + A.m[8] * U.m[7];
+                J[5] += A.m[2] * U.m[2] + A.m[5] * U.m[5] + A.m[8] * U.m[8];
+                if (more) {
+                    const M3 G = m3_mul(A2, W);
+                    const M3 T = m3_mul(G, Cm);
+                    // C12 = (G C1) A2^T + C2
+                    C[0] = C2[0] + (T.m[0] * A2.m[0] + T.m[1] * A2.m[1] + T.m[2] * A2.m[2]);
+                    C[1] = C2[1] + (T.m[3] * A2.m[0] + T.m[4] * A2.m[1] + T.m[5] * A2.m[2]);
+                    C[2] = C2[2] + (T.m[3] * A2.m[3] + T.m[4] * A2.m[4] + T.m[5] * A2.m[5]);
+                    C[3] = C2[3] + (T.m[6] * A2.m[0] + T.m[7] * A2.m[1] + T.m[8] * A2.m[2]);
+                    C[4] = C2[4] + (T.m[6] * A2.m[3] + T.m[7] * A2.m[4] + T.m[8] * A2.m[5]);
+                    C[5] = C2[5] + (T.m[6] * A2.m[6] + T.m[7] * A2.m[7] + T.m[8] * A2.m[8]);
+                    A = m3_mul(G, A);
+                }
+            }
+        }
+        // --- P_{k+1} to the lane of stage k, gains per stage ---
+        P.p00 = lane_next(J[0]); P.p10 = lane_next(J[1]); P.p11 = lane_next(J[2]);
+        P.p20 = lane_next(J[3]); P.p21 = lane_next(J[4]); P.p22 = lane_next(J[5]);
+        Gain g;
+        gain(P, ab, Gam[0], Gam[1], true, g);
+        id0 = g.id0; l10 = g.l10; id1 = g.id1;
+        const bool kk = mid && !is0;
+        K00 = kk ? g.K00 : 0.0; K01 = kk ? g.K01 : 0.0; K02 = kk ? g.K02 : 0.0;
+        K10 = kk ? g.K10 : 0.0; K11 = kk ? g.K11 : 0.0; K12 = kk ? g.K12 : 0.0;
+        // --- affine right-hand side ---
+        const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
+        const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
+        const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
+        rhs_scan(rg[0] + gam[0], rg[1] + gam[1], rg[2] + gam[2], rg[3] + gam[3], q0, q1, q2);
+    }
+
+    // p_k = (hxp + K^T hup) + Phi^T (q + p_{k+1}),  kff = -(Huu)^-1 (hup + B^T (q + p_{k+1}))
+    __device__ __forceinline__ void rhs_scan(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
+        const M3 F = closed_loop();
+        M3 T;   // Phi^T
+        T.m[0] = F.m[0]; T.m[1] = F.m[3]; T.m[2] = F.m[6]; T.m[3] = F.m[1]; T.m[4] = F.m[4]; T.m[5] = F.m[7]; T.m[6] = F.m[2]; T.m[7] = F.m[5]; T.m[8] = F.m[8];
+        double s[3];
+        if (mid) {
+            const double qv[3] = {q0, q1, q2};
+            double r[3];
+            m3_mulv(T, qv, r);
+            s[0] = (hxp0 + (K00 * hup0 + K10 * hup1)) + r[0];
+            s[1] = (hxp1 + (K01 * hup0 + K11 * hup1)) + r[1];
+            s[2] = (rg[4] + (K02 * hup0 + K12 * hup1)) + r[2];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) T.m[i] = 0.0;
+            s[0] = rg[2]; s[1] = rg[3]; s[2] = rg[4];   // lane N: p_N
+        }
+        affine_suffix_scan(T, s);
+        const double p0 = lane_next(s[0]), p1 = lane_next(s[1]), p2 = lane_next(s[2]);
+        if (mid) {
+            pv[0] = p0; pv[1] = p1; pv[2] = p2;
+            const double w0 = q0 + p0, w1 = q1 + p1, w2 = q2 + p2;
+            const double hu0 = hup0 + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
+            const double hu1 = hup1 + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
+            solve2(id0, l10, id1, hu0, hu1, kff[0], kff[1]);
+        }
+    }
+
+    // dx_{k+1} = Phi dx_k + (rb + B kff), dx_0 = 0;  du = kff + K dx
+    __device__ __forceinline__ void fwd_scan(double& nx0, double& nx1, double& nx2, double dl[5]) {
+        M3 M = closed_loop();
+        double v[3];
+        v[0] = rb[0] + (ab.B00 * kff[0] + ab.B01 * kff[1]);
+        v[1] = rb[1] + (ab.B10 * kff[0] + ab.B11 * kff[1]);
+        v[2] = rb[2] + (ab.B20 * kff[0] + ab.B21 * kff[1]);
+        if (!mid) { v[0] = v[1] = v[2] = 0.0; }
+        affine_prefix_scan(M, v);
+        nx0 = v[0]; nx1 = v[1]; nx2 = v[2];
+        double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
+        if (is0) { dx0 = dx1 = dx2 = 0.0; }
+        if (mid) {
+            dl[0] = kff[0] + (K00 * dx0 + K01 * dx1 + K02 * dx2);
+            dl[1] = kff[1] + (K10 * dx0 + K11 * dx1 + K12 * dx2);
+        }
+        if (act) { dl[2] = dx0; dl[3] = dx1; dl[4] = dx2; }
+    }
+
     // ---- BW: corrected complementarity -> new right-hand side, backward.  Lane::sweep_bw.
     __device__ __forceinline__ void bw(int mode, double sigma_mu) {
         double gam[4];
@@ -266,6 +500,11 @@ struct Wave : Algebra {
         const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
         const double hup0 = rg[0] + gam[0], hup1 = rg[1] + gam[1];
         const double hxp0 = rg[2] + gam[2], hxp1 = rg[3] + gam[3];
+        if (SCAN) rhs_scan(hup0, hup1, hxp0, hxp1, q0, q1, q2);
+        else rhs_seq(hup0, hup1, hxp0, hxp1, q0, q1, q2);
+    }
+
+    __device__ __forceinline__ void rhs_seq(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
         double po0 = rg[2], po1 = rg[3], po2 = rg[4];   // meaningful in lane N
         for (int kc = N - 1; kc >= 0; --kc) {
             const double p0 = lane_next(po0), p1 = lane_next(po1), p2 = lane_next(po2);
@@ -287,13 +526,7 @@ struct Wave : Algebra {
         }
     }
 
-    // ---- FW: forward substitution (sequential), then step lengths and the mu_aff sums on all
-    //      stages at once.  Lane::sweep_fw.
-    struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
-    template <bool FINAL>
-    __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o) {
-        double nx0 = 0.0, nx1 = 0.0, nx2 = 0.0;   // dx_{k+1}, produced by the lane of stage k
-        double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    __device__ __forceinline__ void fwd_seq(double& nx0, double& nx1, double& nx2, double dl[5]) {
         for (int kc = 0; kc < N; ++kc) {
             double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
             if (k == kc) {
@@ -314,6 +547,17 @@ struct Wave : Algebra {
             const double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
             if (isN) { dl[2] = dx0; dl[3] = dx1; dl[4] = dx2; }
         }
+    }
+
+    // ---- FW: forward substitution (sequential), then step lengths and the mu_aff sums on all
+    //      stages at once.  Lane::sweep_fw.
+    struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
+    template <bool FINAL>
+    __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o) {
+        double nx0 = 0.0, nx1 = 0.0, nx2 = 0.0;   // dx_{k+1}, produced by the lane of stage k
+        double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (SCAN) fwd_scan(nx0, nx1, nx2, dl);
+        else fwd_seq(nx0, nx1, nx2, dl);
         double a_prim = -1.0, a_dual = -1.0, s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dlam_net[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
