@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one phase-0 launch (65536 x N=50), rocprofv3 PMC passes in profiles/r01 (v3):
-# FETCH_SIZE 22.28 GB x 2 (gfx950 8-B-per-lane correction) + WRITE_SIZE 14.27 GB
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 58.8e9
+# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v4):
+# FETCH_SIZE 1.047e6 KiB x 2 (gfx950 8-B-per-lane correction) + WRITE_SIZE 0.96e6 KiB
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 3.13e9
 
 
 def algorithmic_bytes_per_solve(N):
@@ -146,28 +146,28 @@ def main():
             "failed_instances": int((status_last != 0).sum()),
             "kernel_ms_per_step": mean_kernel_ms,
         }
-        # ---- roofline of the dominant kernel: the dense first k_phase launch of a step ----
-        # (the second launch works on the few-percent stragglers and is latency-bound)
+        # ---- roofline of the dominant kernel: k_wave (one OCP per wavefront, workspace in registers) ----
         from tests import oracle_lib
         f0, f1, trig = flops_model(oracle_lib, sp, wl)
         flops_step = float((f0 + f1 * qp_iter_last).sum())
         bytes_step = algorithmic_bytes_per_solve(N) * B
         p0_ms = float(np.mean(phase0_ms))
         ach_gbs = bytes_step / (p0_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_phase (phase 0)", "launch_ms": p0_ms,
+        traffic = MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (B == 65536 and N == 50) else None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_wave<64,scan>", "launch_ms": p0_ms,
                            "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                           "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (B == 65536 and N == 50) else None,
+                           "traffic": traffic,
                            "note": "achieved = ALGORITHMIC bytes (batch I/O: x0, yref, yref_e in; u0, status, qp_iter out = "
-                                   f"{algorithmic_bytes_per_solve(N)} B/solve) / live HIP-event duration of the launch; traffic = "
-                                   "FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE from profiles/r01/v3_pmc_*.csv: the kernel "
-                                   "is bound by its Riccati/IPM WORKSPACE traffic (4.6 TB/s = 73% of the 6.29 TB/s achievable rate)"}
-        if out["roofline"]["traffic"]:
-            out["roofline"]["hbm_traffic_rate"] = out["roofline"]["traffic"] / (p0_ms * 1e-3) / 1e9  # GB/s actually moved
-        ach_tf = flops_step / (mean_kernel_ms * 1e-3) / 1e12
-        out["roofline_fp64"] = {"bound": "fp64_vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                   f"{algorithmic_bytes_per_solve(N)} B/solve) / live HIP-event duration of the launch; the kernel "
+                                   "keeps the IPM workspace in registers and is bound by FP64 VALU issue, not by HBM: see roofline_fp64"}
+        if traffic:
+            out["roofline"]["hbm_traffic_rate"] = traffic / (p0_ms * 1e-3) / 1e9  # GB/s actually moved
+        ach_tf = flops_step / (p0_ms * 1e-3) / 1e12
+        out["roofline_fp64"] = {"bound": "fp64_vector", "kernel": "k_wave<64,scan>", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                                 "flops_per_solve": flops_step / B, "trig_calls_per_solve": trig,
-                                "model": f"{f0:.0f} + {f1:.0f}*qp_iter (dense oracle op count) over the whole step's device time"}
+                                "model": f"{f0:.0f} + {f1:.0f}*qp_iter (op count of the dense SEQUENTIAL oracle = algorithmic "
+                                         "flops; the parallel scans execute ~3x more) over the k_wave launch"}
         # ---- batch=1 latency (second half of the metric) ----
         if not args.no_latency:
             sp1, wl1 = workload.make(args.variant, 1)

@@ -157,6 +157,20 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
  * sqp_iter [B], res4 [B][4]. */
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 
+/* Execution model of the solve kernels (no counterpart in the reference; results agree to
+ * rounding, ~1e-13, across models).  AUTO = WAVE when it applies, else LANE.
+ *   LANE     one OCP per lane, IPM workspace in HBM (any N <= MPC_MAX_N, full SQP);
+ *   WAVE     one OCP per wavefront (lane = stage), workspace in registers, Riccati recursion
+ *            and the two substitutions as parallel scans (N <= 63, SQP_RTI only);
+ *   WAVE_SEQ same mapping with sequential recursions (cross-check of the scans).
+ * A model that does not apply to the handle's spec falls back to LANE.  The environment
+ * variable MPC_MODEL=lane|wave|waveseq sets the default of handles left on AUTO. */
+#define MPC_MODEL_AUTO 0
+#define MPC_MODEL_LANE 1
+#define MPC_MODEL_WAVE 2
+#define MPC_MODEL_WAVE_SEQ 3
+int mpc_batch_set_model(mpc_batch_t* h, int model);
+
 /* Introspection used by bench/tests: kernel time of the last solve in ms
  * (hipEvents on the handle's stream around the device work), horizon,
  * capacity, and the last HIP error string of this handle. */

@@ -25,7 +25,7 @@ EXPORTS = (
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
-    "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run",
+    "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model",
 )
 
 
@@ -82,6 +82,7 @@ def lib():
     L.mpc_batch_track_set_path.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_int, _dp]
     L.mpc_batch_track_init.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]
     L.mpc_batch_track_run.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip]
+    L.mpc_batch_set_model.argtypes = [_vp, ctypes.c_int]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -195,6 +196,12 @@ class BatchSolver:
         target, status = np.zeros(B, np.int32), np.zeros(B, np.int32)
         self._check(lib().mpc_batch_track_run(self._h, B, n_ticks, _p(x), _p(u), _pi(target), _pi(status)), "mpc_batch_track_run")
         return dict(x=x, u=u, target=target, status=status)
+
+    MODELS = {"auto": 0, "lane": 1, "wave": 2, "waveseq": 3}
+
+    def set_model(self, model):
+        """Execution model of the solve kernels: 'auto', 'lane', 'wave', 'waveseq' (include/mpc_batch.h)."""
+        self._check(lib().mpc_batch_set_model(self._h, self.MODELS[model]), "mpc_batch_set_model")
 
     def reset(self, mask=None):
         if mask is None:

@@ -410,6 +410,7 @@ struct mpc_batch {
     int capacity = 0;
     std::vector<Shard> shards;
     double last_ms = 0.0;
+    int model = MPC_MODEL_AUTO;
     double t_density = 0.0;   // tracker parameters (mpc_batch_track_init)
     int t_limit = 0;
     std::string err;
@@ -478,13 +479,19 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     // Execution model.  MPC_MODEL=lane forces the one-OCP-per-lane kernels (k_phase), =wave the
     // one-OCP-per-wavefront kernel (k_wave; needs N + 1 <= 64 and plain RTI).
     static const char* model_env = getenv("MPC_MODEL");
+    int model = h->model;
+    if (model == MPC_MODEL_AUTO && model_env) {
+        if (strcmp(model_env, "lane") == 0) model = MPC_MODEL_LANE;
+        else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
+        else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
+    }
     const bool wave_ok = !sqp && N + 1 <= MPC_WAVE;
-    const bool use_wave = wave_ok && !(model_env && strcmp(model_env, "lane") == 0);
+    const bool use_wave = wave_ok && model != MPC_MODEL_LANE;
     if (use_wave) {
         HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
         // MPC_MODEL=waveseq: sequential Riccati recursions under a lane predicate instead of
         // the parallel scans (development / cross-check)
-        const bool seq = model_env && strcmp(model_env, "waveseq") == 0;
+        const bool seq = model == MPC_MODEL_WAVE_SEQ;
         const dim3 blk(MPC_WAVE);
         if (N + 1 <= 16) {
             if (seq) hipLaunchKernelGGL((k_wave<16, false>), dim3((n + 3) / 4), blk, 0, st, h->consts, m, n);
@@ -552,7 +559,7 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 
 extern "C" {
 
-const char* mpc_batch_version(void) { return "mpc_amd 0.1 (gfx950, lane-per-OCP FP64)"; }
+const char* mpc_batch_version(void) { return "mpc_amd 0.2 (gfx950 FP64: wave-per-OCP parallel-in-time + lane-per-OCP)"; }
 
 int mpc_spec_variant(const char* name, mpc_ocp_spec_t* s) {
     if (!name || !s) return -1;
@@ -922,6 +929,12 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
     }
     h->last_ms = worst;
     (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_set_model(mpc_batch_t* h, int model) {
+    if (!h || model < MPC_MODEL_AUTO || model > MPC_MODEL_WAVE_SEQ) return -1;
+    h->model = model;
     return 0;
 }
 

@@ -346,3 +346,43 @@ def test_device_closed_loop_matches_per_vehicle_optimizers(oracle):
     r2 = solver2.track_run(30)
     assert np.array_equal(r2["target"], r["target"]) and np.abs(r2["x"] - r["x"]).max() < 1e-12
     solver.close(); solver2.close()
+
+
+@pytest.mark.parametrize("name,B", [("mobile_robot", 2500), ("park", 600), ("mobile_robot_25", 300)])
+def test_execution_models_agree(oracle, name, B):
+    """The three execution models (include/mpc_batch.h MPC_MODEL_*) on the same inputs, cold tick
+    + 2 warm ticks: each within the parity bar of the oracle, same status and iteration counts."""
+    sp, wl = workload.make(name, B)
+    solvers = {}
+    for model in ("lane", "wave", "waveseq"):
+        solvers[model] = capi.BatchSolver(sp, B)
+        solvers[model].set_model(model)
+    xo = uo = None
+    for t in range(3):
+        x0, yref, yref_e = wl.tick(t)
+        ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
+        xo, uo = ro["xtraj"], ro["utraj"]
+        for model, s in solvers.items():
+            rg = s.solve(x0, yref, yref_e)
+            xg, ug, _ = s.get(B, want_pi=False)
+            rg["xtraj"], rg["utraj"] = xg, ug
+            _compare(ro, rg, B)
+    for s in solvers.values():
+        s.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 15, 16, 31, 32, 63])
+def test_wave_model_group_widths(oracle, N):
+    """Horizons at the edges of the 16-/32-/64-lane groups of the wave kernel (several OCPs per
+    wavefront for N <= 31), ragged batch."""
+    B = 37
+    sp, wl = workload.make("mobile_robot", B, N=N)
+    x0, yref, yref_e = wl.tick(0)
+    s = capi.BatchSolver(sp, B)
+    s.set_model("wave")
+    ro = oracle.rti_batch(sp, x0, yref, yref_e)
+    rg = s.solve(x0, yref, yref_e)
+    xg, ug, _ = s.get(B, want_pi=False)
+    rg["xtraj"], rg["utraj"] = xg, ug
+    _compare(ro, rg, B, min_same=0.97)
+    s.close()
