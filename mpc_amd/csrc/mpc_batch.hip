@@ -79,8 +79,8 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // instance's workspace column and writes the new iterate, u0, status back to it; nothing else
 // touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
 // the full wave); a group whose instance has converged is masked by `go`.
-template <int GW, bool SCAN>
-__global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
+template <int GW, bool SCAN, bool SQP>
+__global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B, int sqp_max_iter) {
     constexpr int G = MPC_WAVE / GW;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;
@@ -103,34 +103,117 @@ __global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B) {
     for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? sN[(R_X0 + q) << 6] : 0.0;
 #pragma unroll
     for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
-    w.prepare(xi, ui, x0b);
+    const double u_prev0 = ui[0], u_prev1 = ui[1];
     typename Wave<GW, SCAN>::State s;
-    w.begin(s);
-    for (;;) {
-        const bool go = inst && w.cont(s);
-        if (!__any(go)) break;
-        if (go) w.iterate(s);
-    }
-    // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping), full-step update
-    int hs;
-    if (s.kk == c.iter_max) hs = 1;
-    else if (s.alpha <= c.alpha_min) hs = 2;
-    else if (s.mu != s.mu) hs = 3;
-    else hs = 0;
-    const bool ok = (hs == 0 || hs == 1);
-    if (!on) return;
-    if (k == 0) { m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = ok ? 0 : 4; }
-    if (ok) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = w.z[2 + q];
-        if (k < N) {
-            sk[(R_U + 0) << 6] = w.z[0]; sk[(R_U + 1) << 6] = w.z[1];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = w.pi[q];
+    s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0;
+    s.n.g = s.n.b = s.n.d = s.n.m = s.n.musum = 0.0;
+    int status = 0;
+    if (!SQP) {
+        // ---- SQP_RTI: one linearisation, one QP, full step ----
+        w.prepare(xi, ui, x0b);
+        w.begin(s);
+        for (;;) {
+            const bool go = inst && w.cont(s);
+            if (!__any(go)) break;
+            if (go) w.iterate(s);
         }
-        if (k == 0) { sN[(R_U0 + 0) << 6] = w.z[0]; sN[(R_U0 + 1) << 6] = w.z[1]; }
-    } else if (k == 0) {
-        sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];   // previous u_0 stays in force
+        // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping)
+        int hs;
+        if (s.kk == c.iter_max) hs = 1;
+        else if (s.alpha <= c.alpha_min) hs = 2;
+        else if (s.mu != s.mu) hs = 3;
+        else hs = 0;
+        const bool ok = (hs == 0 || hs == 1);
+        status = ok ? 0 : 4;
+        if (ok) {
+            ui[0] = w.z[0]; ui[1] = w.z[1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xi[q] = w.z[2 + q];
+        }
+        if (!on) return;
+        if (k == 0) { m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = status; }
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
+            if (k < N) {
+                sk[(R_U + 0) << 6] = ui[0]; sk[(R_U + 1) << 6] = ui[1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = w.pi[q];
+            }
+        }
+        if (k == 0) {   // on a QP failure the previous u_0 stays in force
+            sN[(R_U0 + 0) << 6] = ok ? ui[0] : u_prev0;
+            sN[(R_U0 + 1) << 6] = ok ? ui[1] : u_prev1;
+        }
+        return;
+    }
+    // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update;
+    //      the whole loop runs inside the kernel, one OCP per group, no host round trip ----
+    double pin[3], lamn[8], res[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pin[q] = (on && k < N) ? sk[(R_PI + q) << 6] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? sk[(R_LAM + q) << 6] : 0.0;
+    bool running = inst;
+    int sqp_it = 0, qp_it = 0, diag = 0;
+    status = 2;   // MAXITER unless a residual check passes
+    for (;;) {
+        if (running && sqp_it >= sqp_max_iter) running = false;   // MAXITER: no check after the last QP
+        if (running) {
+            double xn[3];
+            w.linearize(xi, ui, xn);
+            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, res);
+            if (res[0] < c.nlp_tol && res[1] < c.nlp_tol && res[2] < c.nlp_tol && res[3] < c.nlp_tol) {
+                status = 0;
+                running = false;
+            }
+        }
+        if (!__any(running)) break;
+        if (running) {
+            w.cold_start(xi, ui, x0b);
+            w.begin(s);
+        }
+        for (;;) {
+            const bool go = running && w.cont(s);
+            if (!__any(go)) break;
+            if (go) w.iterate(s);
+        }
+        if (running) {
+            int hs;
+            if (s.kk == c.iter_max) hs = 1;
+            else if (s.alpha <= c.alpha_min) hs = 2;
+            else if (s.mu != s.mu) hs = 3;
+            else hs = 0;
+            qp_it = s.kk;
+            diag |= s.diag;
+            ++sqp_it;
+            if (hs == 0 || hs == 1) {
+                ui[0] = w.z[0]; ui[1] = w.z[1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { xi[q] = w.z[2 + q]; pin[q] = w.pi[q]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lamn[q] = w.has_bound(q & 3) ? w.bn.lam[q] : 0.0;
+            } else {
+                status = 4;
+                running = false;
+            }
+        }
+    }
+    if (!on) return;
+    if (k == 0) {
+        m.QPITER[i] = qp_it; m.DIAG[i] = diag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
+        sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
+    if (k < N) {
+        sk[(R_U + 0) << 6] = ui[0]; sk[(R_U + 1) << 6] = ui[1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = pin[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sk[(R_LAM + q) << 6] = lamn[q];
     }
 }
 
@@ -485,24 +568,26 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
         else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
     }
-    const bool wave_ok = !sqp && N + 1 <= MPC_WAVE;
+    const bool wave_ok = N + 1 <= MPC_WAVE;
     const bool use_wave = wave_ok && model != MPC_MODEL_LANE;
     if (use_wave) {
-        HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-        // MPC_MODEL=waveseq: sequential Riccati recursions under a lane predicate instead of
-        // the parallel scans (development / cross-check)
-        const bool seq = model == MPC_MODEL_WAVE_SEQ;
+        // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
+        // the parallel scans (development / cross-check; RTI only)
+        const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
         const dim3 blk(MPC_WAVE);
-        if (N + 1 <= 16) {
-            if (seq) hipLaunchKernelGGL((k_wave<16, false>), dim3((n + 3) / 4), blk, 0, st, h->consts, m, n);
-            else hipLaunchKernelGGL((k_wave<16, true>), dim3((n + 3) / 4), blk, 0, st, h->consts, m, n);
-        } else if (N + 1 <= 32) {
-            if (seq) hipLaunchKernelGGL((k_wave<32, false>), dim3((n + 1) / 2), blk, 0, st, h->consts, m, n);
-            else hipLaunchKernelGGL((k_wave<32, true>), dim3((n + 1) / 2), blk, 0, st, h->consts, m, n);
-        } else {
-            if (seq) hipLaunchKernelGGL((k_wave<64, false>), dim3(n), blk, 0, st, h->consts, m, n);
-            else hipLaunchKernelGGL((k_wave<64, true>), dim3(n), blk, 0, st, h->consts, m, n);
-        }
+        const int mi = h->spec.sqp_max_iter;
+        HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+#define MPC_LAUNCH_WAVE(GW_, PER_)                                                                                        \
+        do {                                                                                                              \
+            const dim3 grd((n + (PER_) - 1) / (PER_));                                                                    \
+            if (sqp) hipLaunchKernelGGL((k_wave<GW_, true, true>), grd, blk, 0, st, h->consts, m, n, mi);                 \
+            else if (seq) hipLaunchKernelGGL((k_wave<GW_, false, false>), grd, blk, 0, st, h->consts, m, n, mi);          \
+            else hipLaunchKernelGGL((k_wave<GW_, true, false>), grd, blk, 0, st, h->consts, m, n, mi);                    \
+        } while (0)
+        if (N + 1 <= 16) MPC_LAUNCH_WAVE(16, 4);
+        else if (N + 1 <= 32) MPC_LAUNCH_WAVE(32, 2);
+        else MPC_LAUNCH_WAVE(64, 1);
+#undef MPC_LAUNCH_WAVE
         HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
         s.n_ph = 1;
         HIPCHK(h, hipGetLastError());

@@ -115,7 +115,55 @@ struct Wave : Algebra {
     // ERK4 linearisation + OCP_QP_INIT_VAR cold start of this stage (Lane::prepare)
     __device__ __forceinline__ void prepare(const double xi[3], const double ui[2], const double x0bar[3]) {
         double xn[3];
+        linearize(xi, ui, xn);
+        cold_start(xi, ui, x0bar);
+    }
+    __device__ __forceinline__ void linearize(const double xi[3], const double ui[2], double xn[3]) {
         linearize_math(xi[0], xi[1], xi[2], ui[0], ui[1], ab, cv, xn);
+        if (!mid) { ab.a = ab.b = ab.B00 = ab.B10 = ab.B20 = ab.B01 = ab.B11 = ab.B21 = 0.0; cv[0] = cv[1] = cv[2] = 0.0; }
+    }
+    // NLP residuals of acados' full SQP (Lane::nlp_res_and_linearize, oracle nlp_residuals) at the
+    // iterate (xi, ui) with the multipliers (pin, lamn) of the previous QP; needs linearize() first
+    // (xn = phi(x_k, u_k)).  out = {stat, eq, ineq, comp}, identical in all lanes of the group.
+    __device__ __forceinline__ void nlp_residuals(const double xi[3], const double ui[2], const double x0bar[3],
+                                                  const double xn[3], const double pin[3], const double lamn[8],
+                                                  double out[4]) const {
+        double r_stat = 0.0, r_eq = 0.0, r_ineq = 0.0, r_comp = 0.0;
+        const double zz[5] = {mid ? ui[0] : 0.0, mid ? ui[1] : 0.0, xi[0], xi[1], xi[2]};
+        double g[5];
+        g[0] = c.wg[0] * (zz[0] - yref[3]);
+        g[1] = c.wg[1] * (zz[1] - yref[4]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double pm = lane_prev(pin[q]);
+            if (is0) pm = 0.0;
+            g[2 + q] = (isN ? c.we[q] : c.wg[2 + q]) * (zz[2 + q] - yref[q]) - pm;
+            const double xnext = lane_next(xi[q]);
+            if (mid) r_eq = amax(r_eq, xn[q] - xnext);
+            if (is0) r_ineq = amax(r_ineq, x0bar[q] - xi[q]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (has_bound(j)) {
+                const double dl = c.lb[j] - zz[j], du = zz[j] - c.ub[j];
+                g[j] += lamn[4 + j] - lamn[j];
+                r_ineq = fmax(r_ineq, dl); r_ineq = fmax(r_ineq, du);
+                r_comp = amax(r_comp, lamn[j] * dl); r_comp = amax(r_comp, lamn[4 + j] * du);
+            }
+        }
+        if (mid) {
+            g[0] += ab.B00 * pin[0] + ab.B10 * pin[1] + ab.B20 * pin[2];
+            g[1] += ab.B01 * pin[0] + ab.B11 * pin[1] + ab.B21 * pin[2];
+            g[2] += pin[0]; g[3] += pin[1]; g[4] += ab.a * pin[0] + ab.b * pin[1] + pin[2];
+            r_stat = amax(r_stat, g[0]); r_stat = amax(r_stat, g[1]);
+        }
+        if (act && !is0) { r_stat = amax(r_stat, g[2]); r_stat = amax(r_stat, g[3]); r_stat = amax(r_stat, g[4]); }
+        out[0] = group_reduce<GW>(r_stat, OpMax());
+        out[1] = group_reduce<GW>(r_eq, OpMax());
+        out[2] = group_reduce<GW>(r_ineq, OpMax());
+        out[3] = group_reduce<GW>(r_comp, OpMax());
+    }
+    __device__ __forceinline__ void cold_start(const double xi[3], const double ui[2], const double x0bar[3]) {
         z[0] = mid ? ui[0] : 0.0;
         z[1] = mid ? ui[1] : 0.0;
 #pragma unroll
@@ -149,7 +197,6 @@ struct Wave : Algebra {
         id0 = l10 = id1 = K00 = K01 = K02 = K10 = K11 = K12 = 0.0;
         P.p00 = P.p10 = P.p11 = P.p20 = P.p21 = P.p22 = 0.0;
         rb[0] = rb[1] = rb[2] = 0.0;
-        if (!mid) { ab.a = ab.b = ab.B00 = ab.B10 = ab.B20 = ab.B01 = ab.B11 = ab.B21 = 0.0; cv[0] = cv[1] = cv[2] = 0.0; }
     }
 
     // ---- BU: variable update + residuals (all stages at once) + Riccati factorisation with
@@ -618,7 +665,11 @@ struct Wave : Algebra {
     // ---- the RTI step (Lane::begin / cont / iterate) ----
     __device__ __forceinline__ double nc_inv() const { return 1.0 / (4 + 8 * (c.N - 1)); }
     __device__ __forceinline__ void begin(State& s) {
-        bu<true>(0, 0.0, 0.0, s.n);
+        // with a zero step and alpha = 0 the update half of BU is the identity (cold-start values
+        // are far above the lam/t clamps), so the first residual + factorisation pass shares the
+        // code of the per-iteration one: one copy of the largest block keeps the kernel within
+        // the instruction cache
+        bu<false>(0, 0.0, 0.0, s.n);
         s.mu = s.n.musum * nc_inv();
         s.alpha = 1.0;
         s.kk = 0;
@@ -639,17 +690,20 @@ struct Wave : Algebra {
         const double sigma = tmp * tmp * tmp;
         double sigma_mu = sigma * s.mu;
         if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+        // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
+        // (mode 2).  A loop instead of two inlined copies (code size).
         int mode = 1;
-        bw(1, sigma_mu);
         FwdOut fc;
-        fw<true>(1, sigma_mu, fc);
-        double alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
-        const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
-        if (mu_aff1 > 2.0 * mu_aff0) {   // conditional predictor-corrector: pure centering
-            mode = 2;
-            bw(2, sigma_mu);
-            fw<true>(2, sigma_mu, fc);
+        double alpha = 0.0;
+#pragma nounroll
+        for (;;) {
+            bw(mode, sigma_mu);
+            fw<true>(mode, sigma_mu, fc);
             alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
+            if (mode == 2) break;
+            const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
+            if (!(mu_aff1 > 2.0 * mu_aff0)) break;
+            mode = 2;
         }
         if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF;
         if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;

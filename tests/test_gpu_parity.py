@@ -281,8 +281,9 @@ def test_park_full_size_properties(oracle):
     solver.close()
 
 
+@pytest.mark.parametrize("model", ["wave", "lane"])
 @pytest.mark.parametrize("name,B", [("mobile_robot", 3000), ("park", 300)])
-def test_full_sqp_matches_oracle(oracle, name, B):
+def test_full_sqp_matches_oracle(oracle, name, B, model):
     """BASELINE config 5 (scaled down): sqp_max_iter > 1 = acados-style full SQP with an NLP
     residual exit test.  Same status, same number of QPs, trajectories within the parity bar.
     B = 3000 exercises the phased/compacted path inside every SQP round."""
@@ -290,6 +291,7 @@ def test_full_sqp_matches_oracle(oracle, name, B):
     x0, yref, yref_e = wl.tick(0)
     ro = oracle.sqp_batch(sp, x0, yref, yref_e)
     solver = capi.BatchSolver(sp, B)
+    solver.set_model(model)   # wave: the whole SQP loop inside k_wave; lane: k_nlp_res + phased QP rounds
     rg = solver.solve(x0, yref, yref_e)
     sit, res = solver.get_sqp(B)
     xg, ug, pig = solver.get(B)
