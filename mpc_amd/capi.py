@@ -14,7 +14,7 @@ import numpy as np
 from .variants import OcpSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")  # override: A/B builds in development
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)

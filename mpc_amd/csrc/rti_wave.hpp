@@ -57,8 +57,8 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
     return v;
 }
 // lane i <- lane i+d / lane i-d for any d (ds_bpermute; out-of-range lanes return their own value)
-__device__ __forceinline__ double lane_down(double v, int d) { return __shfl_down(v, d, 64); }
-__device__ __forceinline__ double lane_up(double v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ double lane_down(double v, int d) { return d == 1 ? lane_next(v, v) : __shfl_down(v, d, 64); }
+__device__ __forceinline__ double lane_up(double v, int d) { return d == 1 ? lane_prev(v, v) : __shfl_up(v, d, 64); }
 
 // dense 3x3 helpers for the parallel scans (row-major)
 struct M3 { double m[9]; };
@@ -351,8 +351,10 @@ struct Wave : Algebra {
         for (int d = 1; d < GW; d *= 2) {
             M3 T2;
             double s2[3];
+            if (2 * d < GW) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) T2.m[i] = lane_down(T.m[i], d);
+                for (int i = 0; i < 9; ++i) T2.m[i] = lane_down(T.m[i], d);
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) s2[i] = lane_down(s[i], d);
             if (k + d <= N) {
@@ -370,8 +372,10 @@ struct Wave : Algebra {
         for (int d = 1; d < GW; d *= 2) {
             M3 M1;
             double v1[3];
+            if (2 * d < GW) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) M1.m[i] = lane_up(M.m[i], d);
+                for (int i = 0; i < 9; ++i) M1.m[i] = lane_up(M.m[i], d);
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) v1[i] = lane_up(v[i], d);
             if (k >= d && mid) {
@@ -421,10 +425,14 @@ struct Wave : Algebra {
         for (int d = 1; d < GW; d *= 2) {
             M3 A2;
             double C2[6], J2[6];
+            if (2 * d < GW) {   // the last level only needs J of the right-hand segment
 #pragma unroll
-            for (int i = 0; i < 9; ++i) A2.m[i] = lane_down(A.m[i], d);
+                for (int i = 0; i < 9; ++i) A2.m[i] = lane_down(A.m[i], d);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { C2[i] = lane_down(C[i], d); J2[i] = lane_down(J[i], d); }
+                for (int i = 0; i < 6; ++i) C2[i] = lane_down(C[i], d);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) J2[i] = lane_down(J[i], d);
             if (k + d <= N) {
                 const bool more = 2 * d < GW;   // A and C are only needed by later steps
                 // X = I + C1 J2
