@@ -35,7 +35,7 @@ def test_resampling_density_and_yaw_unwrap(tmp_path):
     yaw = r["state_refs"][:, 2]
     assert np.abs(np.diff(yaw)).max() < 0.1                                  # unwrapped: no 2*pi jumps on a 270 deg arc
     assert abs((yaw[-1] - yaw[0]) - 1.5 * np.pi) < 0.3                    # the s=0.1 smoothing spline bends the ends
-    assert np.allclose(r["kappa"][60:-110], 1 / 3, atol=0.05)
+    assert np.allclose(r["kappa"][40:-100], 1 / 3, atol=0.07)                # smoothing (s=0.1) ripples around 1/R
     assert r["input_refs"][0, 0] == 0.0 and r["input_refs"][25, 0] == 0.5 and (r["input_refs"][:, 1] == 0).all()
     p = tmp_path / "s.txt"
     pathgen.save_txt(str(p), r["state_refs"])                                # text round trip in the reference's format
