@@ -1,0 +1,314 @@
+// optimizer_amd.hpp — C++ drop-in for the reference's `Optimizer` front-end
+// (include/optimizer.hpp:25-457, src/optimizer.cpp) on top of libmpc_amd.so (mpc_batch.h).
+//
+// Same public names, argument meaning and return codes as the reference class:
+//   Optimizer(T, N, v_ref, x_init, y_init, yaw_init); run(); update_and_solve(x, safety_check, mode)
+//   -> 0 ok / 1 solver error, result in u_current[2]; integrate_next_states(); reset_solver();
+//   find_next_waypoint / find_closest_waypoint; update_current_states; set_up_park /
+//   update_and_solve_park -> 0/1/2; transform_point; NearestDirection; loadTxt / saveToFile.
+// Differences, on purpose: the acados capsules, nlp_* pointers and string-keyed setter calls are
+// replaced by two mpc_batch handles of capacity 1; function-statics (limit, lookahead, count)
+// are members, so several Optimizer objects can coexist; the path files are looked up in
+// `paths_dir` (constructor argument / $MPC_PATHS_DIR) instead of a path derived from __FILE__.
+//
+// Vector types: with Eigen available (the reference's build) the Eigen types are used, so
+// `controller.cpp` compiles unchanged against this header; without Eigen a minimal stand-in with
+// the members this class needs (operator(), operator[], rows(), cols(), head<>) is used.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mpc_batch.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>) && !defined(MPC_NO_EIGEN)
+#include <Eigen/Dense>
+#define MPC_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace mpc_amd {
+
+#ifdef MPC_HAVE_EIGEN
+using Vector3d = Eigen::Vector3d;
+using VectorXd = Eigen::VectorXd;
+using MatrixXd = Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+#else
+struct Vector3d {
+    double v[3] = {0, 0, 0};
+    Vector3d() {}
+    Vector3d(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+    const double& operator()(int i) const { return v[i]; }
+    double* data() { return v; }
+    const double* data() const { return v; }
+};
+struct VectorXd {
+    std::vector<double> v;
+    VectorXd() {}
+    explicit VectorXd(int n) : v(n, 0.0) {}
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+    const double& operator()(int i) const { return v[i]; }
+    int size() const { return (int)v.size(); }
+    double* data() { return v.data(); }
+};
+struct MatrixXd {   // row-major
+    int r = 0, c = 0;
+    std::vector<double> v;
+    MatrixXd() {}
+    MatrixXd(int r_, int c_) : r(r_), c(c_), v((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return v[(size_t)i * c + j]; }
+    const double& operator()(int i, int j) const { return v[(size_t)i * c + j]; }
+    int rows() const { return r; }
+    int cols() const { return c; }
+};
+#endif
+
+class Optimizer {
+  public:
+    Optimizer(double T, int N, double v_ref, double x_init = 0.83, double y_init = 0.33, double yaw_init = 1.65756,
+              const std::string& paths_dir = "", const std::string& path_name = "_path1")
+        : T(T), v_ref(v_ref) {
+        (void)N;   // the horizon comes from the solver variant (src/optimizer.cpp:117-123)
+        density = 1 / T / v_ref;
+        region_of_acceptance = 0.03076923 * 3 * (0.125 * 1.3) / density;
+        t0 = 0.0;
+        v_ref_int = (int)(v_ref * 100);
+        const char* variant;
+        if (v_ref_int >= 30) variant = "mobile_robot";
+        else if (v_ref_int == 25) { variant = "mobile_robot_25"; use25 = true; }
+        else if (v_ref_int == 18) { variant = "mobile_robot_18"; use18 = true; }
+        else { std::cerr << "Invalid reference speed, please use 18, 25 or 50" << std::endl; exit(1); }
+        mpc_ocp_spec_t spec, spec_park;
+        if (mpc_spec_variant(variant, &spec) || mpc_spec_variant("park", &spec_park)) exit(1);
+        if (mpc_batch_create(&mpc_, &spec, 1, nullptr, 0)) { printf("mpc_batch_create() failed. Exiting.\n"); exit(1); }
+        if (mpc_batch_create(&mpc_park_, &spec_park, 1, nullptr, 0)) { printf("mpc_batch_create(park) failed. Exiting.\n"); exit(1); }
+        this->N = spec.N; nx = MPC_NX; nu = MPC_NU;
+        N_park = spec_park.N; nx_park = MPC_NX; nu_park = MPC_NU;
+        x_current[0] = x_init; x_current[1] = y_init; x_current[2] = yaw_init;
+        x_real = x_current;
+        std::string dir = paths_dir;
+        if (dir.empty() && getenv("MPC_PATHS_DIR")) dir = getenv("MPC_PATHS_DIR");
+        if (!dir.empty()) {
+            const std::string sfx = path_name + std::to_string(v_ref_int) + ".txt";
+            state_refs = loadTxt(dir + "/state_refs" + sfx);
+            input_refs = loadTxt(dir + "/input_refs" + sfx);
+            set_path_loaded();
+        }
+        if (this->v_ref > 0.3) this->v_ref = 0.35;   // src/optimizer.cpp:174
+    }
+    ~Optimizer() { mpc_batch_free(mpc_); mpc_batch_free(mpc_park_); }
+    Optimizer(const Optimizer&) = delete;
+    Optimizer& operator=(const Optimizer&) = delete;
+
+    // path given directly instead of files
+    void set_path(const MatrixXd& s, const MatrixXd& u) { state_refs = s; input_refs = u; set_path_loaded(); }
+
+    int run() {   // src/optimizer.cpp:177-206
+        int hsy = 0;
+        while (true) {
+            double e2 = 0;
+            for (int q = 0; q < 3; ++q) { const double d = state_refs(num_waypoints - 1, q) - x_current[q]; e2 += d * d; }
+            if (target_waypoint_index > num_waypoints || std::sqrt(e2) < 0.1) break;
+            update_and_solve(x_current);
+            integrate_next_states();
+            hsy++;
+        }
+        return 0;
+    }
+
+    int update_and_solve(Vector3d& i_current_state, bool safety_check = true, int mode = -1) {   // :208-319
+        (void)mode;   // the turn/straight tables of the reference are empty unless loaded
+        find_next_waypoint(target_waypoint_index, i_current_state, safety_check);
+        const int rows = state_refs.rows();
+        const int idx = target_waypoint_index < rows ? target_waypoint_index : rows - 1;
+        std::vector<double> yref((size_t)N * 5, 0.0);
+        double yref_e[3] = {state_refs(target_waypoint_index, 0), state_refs(target_waypoint_index, 1),
+                            state_refs(target_waypoint_index, 2)};   // terminal ref = first waypoint (:244-251)
+        for (int j = 0; j < N; ++j) {
+            double* y = &yref[(size_t)j * 5];
+            if (target_waypoint_index + j >= rows) {
+                for (int q = 0; q < 3; ++q) y[q] = state_refs(rows - 1, q);
+            } else {
+                for (int q = 0; q < 3; ++q) y[q] = state_refs(idx + j, q);
+                y[3] = input_refs(idx + j, 0);
+            }
+            y[4] = 0.0;   // "set steer rate to 0" (:271)
+        }
+        double u0[2];
+        int st = 0;
+        if (mpc_batch_solve(mpc_, 1, i_current_state.data(), yref.data(), yref_e, u0, nullptr, nullptr, &st, nullptr)) st = 4;
+        status = st;
+        if (status != 0) {
+            std::cout << "ERROR!!! acados acados_ocp_solver returned status " << status << ". Exiting." << std::endl;
+            return 1;
+        }
+        u_current[0] = u0[0]; u_current[1] = u0[1];
+        iter++;
+        return 0;
+    }
+
+    void integrate_next_states() {   // :321-341
+        mpc_batch_sim_step(mpc_, 1, x_current.data(), u_current);
+        t0 += T;
+    }
+
+    int find_closest_waypoint(int min_index = -1, int max_index = -1) {   // :343-382
+        const int rows = state_refs.rows();
+        if (limit_ < 0) limit_ = (int)std::floor(rdb_circumference / (v_ref * T));
+        if (min_index < 0) min_index = std::min(last_waypoint_index, rows - 1);
+        if (max_index < 0) max_index = std::min(target_waypoint_index + limit_, rows - 1);
+        const double cn = x_current[0] * x_current[0] + x_current[1] * x_current[1];
+        double best = std::numeric_limits<double>::max();
+        int closest = -1;
+        for (int i = max_index; i >= min_index; --i) {
+            const double px = state_refs(i, 0), py = state_refs(i, 1);
+            const double d = (px * px + py * py) - 2 * (px * x_current[0] + py * x_current[1]) + cn;
+            if (d < best) { best = d; closest = i; }
+        }
+        return closest;
+    }
+
+    int find_next_waypoint(int& output_target, const Vector3d& i_current_state, bool safety_check = true,
+                           int min_index = -1, int max_index = -1) {   // :384-431
+        (void)safety_check;
+        if (limit_ < 0) limit_ = (int)std::floor(rdb_circumference / (v_ref * T));
+        closest_waypoint_index = find_closest_waypoint(min_index, max_index);
+        const double dx = state_refs(closest_waypoint_index, 0) - i_current_state[0];
+        const double dy = state_refs(closest_waypoint_index, 1) - i_current_state[1];
+        const double dist = std::sqrt(dx * dx + dy * dy);
+        if (dist > 1.2) {
+            min_index = (int)std::max(closest_waypoint_index - dist * density * 1.2, 0.0);
+            closest_waypoint_index = find_closest_waypoint(min_index, max_index);
+        }
+        int target;
+        if (count_ >= 8) { target = closest_waypoint_index + lookahead_; count_ = 0; }
+        else { target = target_waypoint_index + 1; count_++; }
+        output_target = std::min(target, (int)state_refs.rows() - 1);
+        last_waypoint_index = output_target;
+        return 1;
+    }
+
+    int update_current_states(double x, double y, double yaw, Vector3d& state, bool safety_check = true) {   // :432-455
+        (void)safety_check;
+        if (closest_waypoint_index < state_refs.rows() && state_refs.rows() > 0) {
+            const double ref_yaw = state_refs(closest_waypoint_index, 2);
+            while (ref_yaw - yaw > M_PI) yaw += 2 * M_PI;
+            while (ref_yaw - yaw < -M_PI) yaw -= 2 * M_PI;
+        }
+        state[0] = x; state[1] = y; state[2] = yaw;
+        return 1;
+    }
+    int update_current_states(double x, double y, double yaw) { return update_current_states(x, y, yaw, x_current); }
+
+    int reset_solver() { return mpc_batch_reset(mpc_, nullptr); }   // include/optimizer.hpp:446-456
+
+    // ---- parking (include/optimizer.hpp:140-267) ----
+    void transform_point(const Vector3d& pt, Vector3d& pt_transformed, const Vector3d& f1, const Vector3d& f2) const {
+        const double xt = pt[0] - f1[0], yt = pt[1] - f1[1];
+        const double rot = f2[2] - f1[2];
+        const double c = std::cos(rot), s = std::sin(rot);
+        const double rx = c * xt - s * yt, ry = s * xt + c * yt;
+        pt_transformed[2] = std::fmod(pt[2] + rot, 2 * M_PI);
+        pt_transformed[0] = rx + f2[0];
+        pt_transformed[1] = ry + f2[1];
+    }
+    static double NearestDirection(double yaw) {
+        while (yaw > 2 * M_PI) yaw -= 2 * M_PI;
+        while (yaw < 0) yaw += 2 * M_PI;
+        static const double directions[5] = {0, M_PI / 2, M_PI, 3 * M_PI / 2, 2 * M_PI};
+        double minDifference = std::abs(yaw - directions[0]);
+        double nearest = directions[0];
+        for (int i = 1; i < 5; ++i) {
+            const double d = std::abs(yaw - directions[i]);
+            if (d < minDifference) { minDifference = d; nearest = directions[i]; }
+        }
+        while (nearest - yaw > M_PI) nearest -= 2 * M_PI;
+        while (nearest - yaw < -M_PI) nearest += 2 * M_PI;
+        return nearest;
+    }
+    void set_up_park(const double xs[5]) {
+        mpc_batch_reset(mpc_park_, nullptr);
+        for (int q = 0; q < 5; ++q) park_xs_[q] = xs[q];
+        frame1[0] = x_current[0]; frame1[1] = x_current[1]; frame1[2] = NearestDirection(x_current[2]);
+        frame2[0] = frame2[1] = frame2[2] = 0.0;
+    }
+    int update_and_solve_park(const double xs[5], double thresh_sq = 0.0025) {
+        transform_point(x_current, x_current_transformed, frame1, frame2);
+        while (x_current_transformed[2] - frame2[2] > M_PI) x_current_transformed[2] -= 2 * M_PI;
+        while (x_current_transformed[2] - frame2[2] < -M_PI) x_current_transformed[2] += 2 * M_PI;
+        double e2 = 0;
+        for (int q = 0; q < 3; ++q) { const double d = x_current_transformed[q] - xs[q]; e2 += d * d; }
+        if (e2 < thresh_sq) return 2;
+        std::vector<double> yref((size_t)N_park * 5);
+        for (int j = 0; j < N_park; ++j) for (int q = 0; q < 5; ++q) yref[(size_t)j * 5 + q] = park_xs_[q];
+        double u0[2];
+        int st = 0;
+        if (mpc_batch_solve(mpc_park_, 1, x_current_transformed.data(), yref.data(), park_xs_, u0, nullptr, nullptr, &st, nullptr)) st = 4;
+        status = st;
+        if (status != 0) return 1;
+        u_current[0] = u0[0]; u_current[1] = u0[1];
+        return 0;
+    }
+
+    // ---- text I/O (src/optimizer.cpp:532-577) ----
+    static MatrixXd loadTxt(const std::string& filename) {
+        std::ifstream file(filename);
+        if (!file.is_open()) throw std::runtime_error("Unable to open file: " + filename);
+        std::string line;
+        std::vector<double> entries;
+        int numRows = 0, numCols = -1;
+        while (std::getline(file, line)) {
+            std::istringstream iss(line);
+            double num;
+            int n = 0;
+            while (iss >> num) { entries.push_back(num); ++n; }
+            if (numCols == -1) numCols = n;
+            else if (n != numCols) throw std::runtime_error("Inconsistent number of columns");
+            numRows++;
+        }
+        MatrixXd m(numRows, numCols < 0 ? 0 : numCols);
+        for (int i = 0; i < numRows; ++i) for (int j = 0; j < numCols; ++j) m(i, j) = entries[(size_t)i * numCols + j];
+        return m;
+    }
+    static void saveToFile(const MatrixXd& data, const std::string& file_path) {
+        std::ofstream file(file_path);
+        if (!file.is_open()) { std::cerr << "Unable to open file: " << file_path << std::endl; return; }
+        for (int i = 0; i < data.rows(); ++i) {
+            for (int j = 0; j < data.cols(); ++j) file << (j ? " " : "") << data(i, j);
+            file << "\n";
+        }
+    }
+
+    // public state, names as in the reference
+    int status = 0;
+    double T, v_ref, density, region_of_acceptance, t0;
+    int N = 0, nx = 0, nu = 0, N_park = 0, nx_park = 0, nu_park = 0, iter = 0, v_ref_int = 0;
+    bool use25 = false, use18 = false, debug = true;
+    int target_waypoint_index = 0, last_waypoint_index = 0, closest_waypoint_index = 0, num_waypoints = 0;
+    Vector3d x_current, x_real, frame1, frame2, x_current_transformed;
+    double u_current[2] = {0.0, 0.0};
+    MatrixXd state_refs, input_refs;
+    static constexpr double rdb_circumference = 3.95;
+
+  private:
+    void set_path_loaded() { num_waypoints = state_refs.rows(); }
+    mpc_batch_t* mpc_ = nullptr;
+    mpc_batch_t* mpc_park_ = nullptr;
+    int limit_ = -1, lookahead_ = 1, count_ = 0;   // function-statics of the reference, per object
+    double park_xs_[5] = {0, 0, 0, 0, 0};
+};
+
+}  // namespace mpc_amd

@@ -388,3 +388,44 @@ def test_wave_model_group_widths(oracle, N):
     rg["xtraj"], rg["utraj"] = xg, ug
     _compare(ro, rg, B, min_same=0.97)
     s.close()
+
+
+def test_cpp_optimizer_shim():
+    """The C++ drop-in `mpc_amd::Optimizer` (include/optimizer_amd.hpp; same public surface as the
+    reference's include/optimizer.hpp) run as a separate process on the recorded path head, against
+    the Python mirror driving the same library: identical waypoint decisions, commands and states."""
+    import os
+    import subprocess
+    from mpc_amd.optimizer import Optimizer, load_txt
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "_build", "optimizer_shim_main")
+    assert os.path.exists(exe), "build it with `make -C tests/cpp` (done by __graft_entry__.build())"
+    sf = os.path.join(here, "golden", "state_refs_path150_head.txt")
+    uf = os.path.join(here, "golden", "input_refs_path150_head.txt")
+    n = 80
+    out = subprocess.run([exe, sf, uf, str(n)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l.split() for l in out.stdout.strip().splitlines()]
+    s, u = load_txt(sf), load_txt(uf)
+    o = Optimizer(0.1, 40, 0.5, *s[0], state_refs=s, input_refs=u)
+    for k in range(n):
+        rc = o.update_and_solve(o.x_current)
+        o.integrate_next_states()
+        row = lines[k]
+        assert int(row[0]) == rc and int(row[1]) == o.target_waypoint_index
+        got = np.array([float(v) for v in row[2:7]])
+        assert np.abs(got - np.concatenate([o.u_current, o.x_current])).max() < 1e-12, k
+    xs = np.array([0.63, 0.32, 0.0, 0.0, 0.0])
+    o.x_current = np.array([3.0, 2.0, 0.05])
+    o.set_up_park(xs)
+    rc, k = 0, 0
+    while k < 400:
+        rc = o.update_and_solve_park(xs)
+        if rc != 0:
+            break
+        o.x_current = o._solver_park.sim_step(o.x_current.reshape(1, 3), o.u_current.reshape(1, 2))[0]
+        k += 1
+    park = lines[n]
+    assert park[0] == "park" and int(park[1]) == rc == 2 and int(park[2]) == k
+    assert np.abs(np.array([float(v) for v in park[3:6]]) - o.x_current_transformed).max() < 1e-12
+    o.close()
