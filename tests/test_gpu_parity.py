@@ -429,3 +429,47 @@ def test_cpp_optimizer_shim():
     assert park[0] == "park" and int(park[1]) == rc == 2 and int(park[2]) == k
     assert np.abs(np.array([float(v) for v in park[3:6]]) - o.x_current_transformed).max() < 1e-12
     o.close()
+
+
+def test_config1_closed_loop_n18_variant():
+    """BASELINE config 1: the `mobile_robot_18` variant (N=40, Ts=0.125, v_ref 0.18) in a single
+    closed-loop run, batch = 1, on references produced by mpc_amd/pathgen.py from an S-shaped run;
+    GPU library vs oracle tick by tick."""
+    from mpc_amd import pathgen
+    from mpc_amd.optimizer import Optimizer
+    from tests.oracle_solver import OracleSolver
+    t = np.linspace(0, 1, 40)
+    run = np.vstack((4.0 * t, 0.8 * np.sin(2 * np.pi * t))).T
+    T, v_ref = 0.125, 0.18
+    ref = pathgen.references([run], v_ref, 40, T, resample=True)
+    s, u = ref["state_refs"], ref["input_refs"]
+    og = Optimizer(T, 40, v_ref, *s[0], state_refs=s, input_refs=u)
+    oo = Optimizer(T, 40, v_ref, *s[0], state_refs=s, input_refs=u, solver_factory=OracleSolver)
+    assert og.variant == "mobile_robot_18" and og.N == 40
+    for k in range(100):
+        assert og.update_and_solve(og.x_current) == 0 and oo.update_and_solve(oo.x_current) == 0
+        assert og.target_waypoint_index == oo.target_waypoint_index
+        assert np.abs(og.u_current - oo.u_current).max() < TOL_HARD, k
+        og.integrate_next_states(); oo.integrate_next_states()
+        assert np.abs(og.x_current - oo.x_current).max() < TOL_HARD, k
+    d = np.hypot(s[:, 0] - og.x_current[0], s[:, 1] - og.x_current[1]).min()
+    assert d < 0.08 and og.x_current[0] > 1.0       # it follows the path and makes progress
+    og.close()
+
+
+def test_config2_batch_4096_n25_variant(oracle):
+    """BASELINE config 2: mobile_robot_25 constants at horizon 25 (two OCPs per wavefront in the
+    wave model), 4096 random initial states / references, cold + warm tick."""
+    B = 4096
+    sp, wl = workload.make("mobile_robot_25", B, N=25)
+    solver = capi.BatchSolver(sp, B)
+    xo = uo = None
+    for t in range(2):
+        x0, yref, yref_e = wl.tick(t)
+        ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
+        xo, uo = ro["xtraj"], ro["utraj"]
+        rg = solver.solve(x0, yref, yref_e)
+        xg, ug, _ = solver.get(B, want_pi=False)
+        rg["xtraj"], rg["utraj"] = xg, ug
+        _compare(ro, rg, B)
+    solver.close()
