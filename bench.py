@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--variant", default="mobile_robot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal of the multi-rank flow)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,11 +75,16 @@ def main():
     import torch.distributed as dist
     from mpc_amd import capi, workload
 
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, K, W = args.batch, args.steps, args.warmup
     sp, wl = workload.make(args.variant, B, first=rank * B)
@@ -124,7 +131,7 @@ def main():
     qp_iter_last = d_it.cpu().numpy()
     status_last = d_st.cpu().numpy()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

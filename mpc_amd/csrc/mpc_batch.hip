@@ -21,6 +21,9 @@ using namespace mpc;
 
 #define MPC_WAVE 64
 #define MPC_MAX_PHASES 8
+#ifndef MPC_WAVE_OCC
+#define MPC_WAVE_OCC 1   /* min waves per SIMD the wave kernel is compiled for */
+#endif
 // Phase schedule: batches up to this size run as one phase (latency path)
 #define MPC_SINGLE_PHASE_MAX 2048
 
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
 // the full wave); a group whose instance has converged is masked by `go`.
 template <int GW, bool SCAN, bool SQP>
-__global__ __launch_bounds__(MPC_WAVE) void k_wave(Consts c, Mem m, int B, int sqp_max_iter) {
+__global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m, int B, int sqp_max_iter) {
     constexpr int G = MPC_WAVE / GW;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;

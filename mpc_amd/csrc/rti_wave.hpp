@@ -100,6 +100,7 @@ struct Wave : Algebra {
     double pv[3], kff[2];
     double id0, l10, id1, K00, K01, K02, K10, K11, K12;
     double dza[4], dz[5], dpi[3];
+    double ti[8];                // 1 / t of the current slacks (same bits as recomputing it in every pass)
 
     struct State {
         int kk, diag;
@@ -111,6 +112,16 @@ struct Wave : Algebra {
         act = k <= N; mid = k < N; isN = k == N; is0 = k == 0;
     }
     __device__ __forceinline__ bool has_bound(int j) const { return mid && (j < 2 || !is0); }
+    // Algebra::con_make with the cached reciprocals
+    __device__ __forceinline__ void con_cached(int j, Con& q) const {
+        q.lam_l = bn.lam[j]; q.lam_u = bn.lam[4 + j]; q.t_l = bn.t[j]; q.t_u = bn.t[4 + j];
+        q.rd_l = c.lb[j] + q.t_l - z[j];
+        q.rd_u = q.t_u + z[j] - c.ub[j];
+        q.rm_l = q.lam_l * q.t_l;
+        q.rm_u = q.lam_u * q.t_u;
+        q.ti_l = ti[j];
+        q.ti_u = ti[4 + j];
+    }
 
     // ERK4 linearisation + OCP_QP_INIT_VAR cold start of this stage (Lane::prepare)
     __device__ __forceinline__ void prepare(const double xi[3], const double ui[2], const double x0bar[3]) {
@@ -180,10 +191,12 @@ struct Wave : Algebra {
             if (has_bound(j)) {
                 z[j] = zj;
                 bn.t[j] = tl; bn.t[4 + j] = tu;
-                bn.lam[j] = c.mu0 * rcp(tl); bn.lam[4 + j] = c.mu0 * rcp(tu);
+                ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
+                bn.lam[j] = c.mu0 * ti[j]; bn.lam[4 + j] = c.mu0 * ti[4 + j];
             } else {
                 bn.t[j] = 1.0; bn.t[4 + j] = 1.0;
                 bn.lam[j] = 0.0; bn.lam[4 + j] = 0.0;
+                ti[j] = 1.0; ti[4 + j] = 1.0;
             }
         }
         pi[0] = pi[1] = pi[2] = 0.0;
@@ -207,7 +220,7 @@ struct Wave : Algebra {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 Con q;
-                con_make(j, bn.lam[j], bn.lam[4 + j], bn.t[j], bn.t[4 + j], z[j], q);
+                con_cached(j, q);
                 con_correct(q, mode, dza[j], sigma_mu);
                 Step s;
                 con_step(q, dz[j], s);
@@ -217,7 +230,10 @@ struct Wave : Algebra {
                 if (lu < c.lam_min) lu = c.lam_min;
                 if (tl < c.t_min) tl = c.t_min;
                 if (tu < c.t_min) tu = c.t_min;
-                if (has_bound(j)) { bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu; }
+                if (has_bound(j)) {
+                    bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
+                    ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 5; ++q) z[q] = z[q] + alpha * dz[q];
@@ -241,7 +257,7 @@ struct Wave : Algebra {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_make(j, bn.lam[j], bn.lam[4 + j], bn.t[j], bn.t[4 + j], z[j], q);
+            con_cached(j, q);
             const bool hb = has_bound(j);
             if (hb) {
                 rg[j] += q.lam_u - q.lam_l;
@@ -546,7 +562,7 @@ struct Wave : Algebra {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_make(j, bn.lam[j], bn.lam[4 + j], bn.t[j], bn.t[4 + j], z[j], q);
+            con_cached(j, q);
             con_correct(q, mode, dza[j], sigma_mu);
             gam[j] = has_bound(j) ? con_gamma(q) : 0.0;
         }
@@ -613,20 +629,23 @@ struct Wave : Algebra {
         double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (SCAN) fwd_scan(nx0, nx1, nx2, dl);
         else fwd_seq(nx0, nx1, nx2, dl);
-        double a_prim = -1.0, a_dual = -1.0, s1 = 0.0, s2 = 0.0, lin_g = 0.0;
+        double pn = 1.0, pd = -1.0, dn = 1.0, dd = -1.0;   // step-length candidates as ratios n / d = -1
+        double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dlam_net[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_make(j, bn.lam[j], bn.lam[4 + j], bn.t[j], bn.t[4 + j], z[j], q);
+            con_cached(j, q);
             if (FINAL) con_correct(q, mode, dza[j], sigma_mu);
             Step s;
             con_step(q, dl[j], s);
             if (has_bound(j)) {
-                if (a_dual * s.dl_l > q.lam_l) a_dual = q.lam_l * rcp(s.dl_l);
-                if (a_prim * s.dt_l > q.t_l) a_prim = q.t_l * rcp(s.dt_l);
-                if (a_dual * s.dl_u > q.lam_u) a_dual = q.lam_u * rcp(s.dl_u);
-                if (a_prim * s.dt_u > q.t_u) a_prim = q.t_u * rcp(s.dt_u);
+                // COMPUTE_ALPHA_QP's running rule "if (a * dv > v) a = v / dv" with a = n / d, d < 0,
+                // compared by cross-multiplication: one reciprocal per lane instead of one per bound
+                if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
+                if (pn * s.dt_l < q.t_l * pd) { pn = q.t_l; pd = s.dt_l; }
+                if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
+                if (pn * s.dt_u < q.t_u * pd) { pn = q.t_u; pd = s.dt_u; }
                 s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
                 s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
                 s2 += s.dl_l * s.dt_l;
@@ -663,6 +682,7 @@ struct Wave : Algebra {
             for (int q = 0; q < 4; ++q) dza[q] = dl[q];
         }
         // the running values are negative ratios in (-1, 0]: the binding one is the largest
+        const double a_prim = pn * rcp(pd), a_dual = dn * rcp(dd);
         o.a_prim = -group_reduce<GW>(a_prim, OpMax());
         o.a_dual = -group_reduce<GW>(a_dual, OpMax());
         o.s1 = group_reduce<GW>(s1, OpSum());
