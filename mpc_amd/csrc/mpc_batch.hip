@@ -82,8 +82,21 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // instance's workspace column and writes the new iterate, u0, status back to it; nothing else
 // touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
 // the full wave); a group whose instance has converged is masked by `go`.
+// Optional direct batch I/O of k_wave in the C-ABI's AoS layouts (device pointers, any may be
+// null): inputs are then read straight from the caller's arrays (lane k reads yref[i][k][0..4],
+// coalesced) instead of from packed workspace rows, and u0 / status / qp_iter are written
+// straight back — no k_pack / k_unpack launches on the wave path.
+struct WaveIO {
+    const double* x0;      // [B][3]
+    const double* yref;    // [B][N][5]
+    const double* yref_e;  // [B][3]
+    double* u0;            // [B][2]
+    int* status;           // [B]
+    int* qp_iter;          // [B]
+};
+
 template <int GW, bool SCAN, bool SQP>
-__global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m, int B, int sqp_max_iter) {
+__global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
     constexpr int G = MPC_WAVE / GW;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;
@@ -102,10 +115,18 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
     for (int q = 0; q < 3; ++q) xi[q] = on ? sk[(R_X + q) << 6] : 0.0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) ui[q] = (on && k < N) ? sk[(R_U + q) << 6] : 0.0;
+    if (io.yref) {
+        const double* yr = k < N ? io.yref + ((size_t)ic * N + kcl) * 5 : io.yref_e + (size_t)ic * 3;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? sN[(R_X0 + q) << 6] : 0.0;
+        for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? io.x0[3 * ic + q] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
+        for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? yr[q] : 0.0;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? sN[(R_X0 + q) << 6] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
+    }
     const double u_prev0 = ui[0], u_prev1 = ui[1];
     typename Wave<GW, SCAN>::State s;
     s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0;
@@ -134,7 +155,12 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
             for (int q = 0; q < 3; ++q) xi[q] = w.z[2 + q];
         }
         if (!on) return;
-        if (k == 0) { m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = status; }
+        if (k == 0) {
+            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = status;
+            if (io.status) io.status[i] = status;
+            if (io.qp_iter) io.qp_iter[i] = s.kk;
+            if (io.u0) { io.u0[2 * i] = ok ? ui[0] : u_prev0; io.u0[2 * i + 1] = ok ? ui[1] : u_prev1; }
+        }
         if (ok) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
@@ -208,6 +234,9 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
 #pragma unroll
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
         sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];
+        if (io.status) io.status[i] = status;
+        if (io.qp_iter) io.qp_iter[i] = qp_it;
+        if (io.u0) { io.u0[2 * i] = ui[0]; io.u0[2 * i + 1] = ui[1]; }
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
@@ -527,7 +556,9 @@ static void free_shard(Shard& s) {
 }
 
 static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
-static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st);
+struct WaveIO;
+static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO* io = nullptr);
+static int pick_model(const mpc_batch* h);
 
 // Enqueue the device work of one solve on shard s for its first `n` instances; all pointers
 // are device pointers in the C-ABI's AoS layouts (any of the optional ones may be null).
@@ -537,13 +568,20 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     const int N = h->spec.N;
     const dim3 tb(32, 8);
     Mem& m = s.mem;
-    hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_x0, 1, 3, N, (int)R_X0, m, n);
-    hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
-    hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
+    const bool wave = pick_model(h) != MPC_MODEL_LANE;
+    if (!wave) {
+        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_x0, 1, 3, N, (int)R_X0, m, n);
+        hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
+        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
+    }
     if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
-    int rc = enqueue_core(h, s, n, st);
+    WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
+    int rc = enqueue_core(h, s, n, st, wave ? &io : nullptr);
     if (rc != 0) return rc;
+    if (wave) {   // inputs and u0 / status / qp_iter went through k_wave directly
+        d_u0 = nullptr; d_status = nullptr; d_iter = nullptr;
+    }
     if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
     if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
     if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
@@ -555,15 +593,8 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
 
 // The solve proper on inputs already in the workspace rows (R_X0, R_YREF, R_YREFE; iterate in
 // R_X, R_U): one RTI step, or the full SQP loop.
-static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
-    const int N = h->spec.N;
-    Mem& m = s.mem;
-    const bool sqp = h->spec.sqp_max_iter > 1;
-    const int iters = sqp ? h->spec.sqp_max_iter : 1;
-    const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
-    s.sqp_rounds = 0;
-    // Execution model.  MPC_MODEL=lane forces the one-OCP-per-lane kernels (k_phase), =wave the
-    // one-OCP-per-wavefront kernel (k_wave; needs N + 1 <= 64 and plain RTI).
+// MPC_MODEL_LANE or a wave model, after AUTO / environment / applicability are resolved
+static int pick_model(const mpc_batch* h) {
     static const char* model_env = getenv("MPC_MODEL");
     int model = h->model;
     if (model == MPC_MODEL_AUTO && model_env) {
@@ -571,21 +602,35 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st) {
         else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
     }
-    const bool wave_ok = N + 1 <= MPC_WAVE;
-    const bool use_wave = wave_ok && model != MPC_MODEL_LANE;
+    if (model == MPC_MODEL_AUTO) model = MPC_MODEL_WAVE;
+    if (h->spec.N + 1 > MPC_WAVE) model = MPC_MODEL_LANE;
+    return model;
+}
+
+static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO* io) {
+    const int N = h->spec.N;
+    Mem& m = s.mem;
+    const bool sqp = h->spec.sqp_max_iter > 1;
+    const int iters = sqp ? h->spec.sqp_max_iter : 1;
+    const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
+    s.sqp_rounds = 0;
+    const int model = pick_model(h);
+    const bool use_wave = model != MPC_MODEL_LANE;
     if (use_wave) {
         // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
         // the parallel scans (development / cross-check; RTI only)
         const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
         const dim3 blk(MPC_WAVE);
         const int mi = h->spec.sqp_max_iter;
+        WaveIO wio;
+        if (io) wio = *io; else memset(&wio, 0, sizeof(wio));
         HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
 #define MPC_LAUNCH_WAVE(GW_, PER_)                                                                                        \
         do {                                                                                                              \
             const dim3 grd((n + (PER_) - 1) / (PER_));                                                                    \
-            if (sqp) hipLaunchKernelGGL((k_wave<GW_, true, true>), grd, blk, 0, st, h->consts, m, n, mi);                 \
-            else if (seq) hipLaunchKernelGGL((k_wave<GW_, false, false>), grd, blk, 0, st, h->consts, m, n, mi);          \
-            else hipLaunchKernelGGL((k_wave<GW_, true, false>), grd, blk, 0, st, h->consts, m, n, mi);                    \
+            if (sqp) hipLaunchKernelGGL((k_wave<GW_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);            \
+            else if (seq) hipLaunchKernelGGL((k_wave<GW_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);     \
+            else hipLaunchKernelGGL((k_wave<GW_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);               \
         } while (0)
         if (N + 1 <= 16) MPC_LAUNCH_WAVE(16, 4);
         else if (N + 1 <= 32) MPC_LAUNCH_WAVE(32, 2);
