@@ -189,7 +189,7 @@ def main():
             s1.close()
             out["latency_b1_ms"] = {"p50": float(np.percentile(lat[10:], 50)), "p99": float(np.percentile(lat[10:], 99)),
                                     "kernel_p50": float(np.percentile(klat[10:], 50)),
-                                    "note": "host pointers in/out, includes H2D/D2H"}
+                                    "note": "mpc_batch_solve with host pointers in/out, end to end (inputs staged in pinned host memory the kernel reads directly)"}
         # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample ----
         if not args.no_cpu_baseline:
             nthr = min(oracle_lib.lib().oracle_max_threads(), 16)

@@ -26,6 +26,9 @@ using namespace mpc;
 #endif
 // Phase schedule: batches up to this size run as one phase (latency path)
 #define MPC_SINGLE_PHASE_MAX 2048
+// Batches up to this size go through pinned host memory that the kernel reads and writes
+// directly (no H2D / D2H copies): the batch = 1 control-loop path
+#define MPC_ZEROCOPY_MAX 64
 
 // ------------------------------------------------------------------------------------
 // kernels
@@ -513,6 +516,9 @@ struct Shard {
     double *s_x0 = nullptr, *s_yref = nullptr, *s_yrefe = nullptr, *s_u0 = nullptr;
     double *s_xt = nullptr, *s_ut = nullptr, *s_pi = nullptr;
     unsigned char* s_mask = nullptr;
+    // pinned, device-visible host staging for small batches (zero-copy latency path)
+    double* z_in = nullptr;   // x0 [Z][3] | yref [Z][N][5] | yref_e [Z][3]
+    double* z_out = nullptr;  // u0 [Z][2] | status [Z] (int) | qp_iter [Z] (int)
     // closed-loop tracker (mpc_batch_track_*): path table and per-vehicle state
     double *t_sref = nullptr, *t_iref = nullptr, *t_x = nullptr, *t_u = nullptr;
     int* t_idx = nullptr;
@@ -547,6 +553,8 @@ static void free_shard(Shard& s) {
     (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
+    if (s.z_in) (void)hipHostFree(s.z_in);
+    if (s.z_out) (void)hipHostFree(s.z_out);
     (void)hipFree(s.t_sref); (void)hipFree(s.t_iref); (void)hipFree(s.t_x); (void)hipFree(s.t_u); (void)hipFree(s.t_idx);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -785,6 +793,11 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipMalloc(&s.s_ut, sizeof(double) * 2 * N * capa));
             HIPCHK(h, hipMalloc(&s.s_pi, sizeof(double) * 3 * N * capa));
             HIPCHK(h, hipMalloc(&s.s_mask, capa));
+            {
+                const size_t Z = capa < MPC_ZEROCOPY_MAX ? capa : MPC_ZEROCOPY_MAX;
+                HIPCHK(h, hipHostMalloc((void**)&s.z_in, sizeof(double) * Z * (6 + 5 * (size_t)N), hipHostMallocMapped));
+                HIPCHK(h, hipHostMalloc((void**)&s.z_out, sizeof(double) * Z * 3, hipHostMallocMapped));
+            }
             HIPCHK(h, hipStreamSynchronize(s.stream));
             return 0;
         };
@@ -834,6 +847,35 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
     const int N = h->spec.N;
     int prev = 0;
     (void)hipGetDevice(&prev);
+    if (h->shards.size() == 1 && B <= MPC_ZEROCOPY_MAX && !xtraj && pick_model(h) != MPC_MODEL_LANE) {
+        // latency path (the reference's batch = 1 control loop): inputs are staged in pinned
+        // host memory that k_wave reads directly, outputs are written straight into pinned
+        // host memory — one launch and one synchronisation, no copies
+        Shard& s = h->shards[0];
+        HIPCHK(h, hipSetDevice(s.device));
+        double* zx0 = s.z_in;
+        double* zyr = zx0 + 3 * (size_t)B;
+        double* zye = zyr + 5 * (size_t)N * B;
+        memcpy(zx0, x0, sizeof(double) * 3 * B);
+        memcpy(zyr, yref, sizeof(double) * 5 * N * B);
+        memcpy(zye, yref_e, sizeof(double) * 3 * B);
+        double* zu0 = s.z_out;
+        int* zst = reinterpret_cast<int*>(zu0 + 2 * (size_t)B);
+        int* zit = zst + B;
+        WaveIO io = {zx0, zyr, zye, zu0, zst, zit};
+        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+        int rc = enqueue_core(h, s, B, s.stream, &io);
+        if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
+        if (status) memcpy(status, zst, sizeof(int) * B);
+        if (qp_iter) memcpy(qp_iter, zit, sizeof(int) * B);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) h->last_ms = ms;
+        (void)hipSetDevice(prev);
+        return 0;
+    }
     // enqueue on every shard, then wait for all: shards run concurrently
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
