@@ -111,13 +111,14 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
     double* col = reinterpret_cast<double*>(m.slab + (ic >> 6) * m.wave_bytes) + (ic & 63);
     double* sk = col + ((size_t)(kcl * MPC_RPS) << 6);
     double* sN = col + ((size_t)(N * MPC_RPS) << 6);
+    double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     Wave<GW, SCAN> w(c, k);
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) xi[q] = on ? sk[(R_X + q) << 6] : 0.0;
+    for (int q = 0; q < 3; ++q) xi[q] = on ? ck[C_X + q] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) ui[q] = (on && k < N) ? sk[(R_U + q) << 6] : 0.0;
+    for (int q = 0; q < 2; ++q) ui[q] = (on && k < N) ? ck[C_U + q] : 0.0;
     if (io.yref) {
         const double* yr = k < N ? io.yref + ((size_t)ic * N + kcl) * 5 : io.yref_e + (size_t)ic * 3;
 #pragma unroll
@@ -166,11 +167,11 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
         }
         if (ok) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
+            for (int q = 0; q < 3; ++q) ck[C_X + q] = xi[q];
             if (k < N) {
-                sk[(R_U + 0) << 6] = ui[0]; sk[(R_U + 1) << 6] = ui[1];
+                ck[C_U + 0] = ui[0]; ck[C_U + 1] = ui[1];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = w.pi[q];
+                for (int q = 0; q < 3; ++q) ck[C_PI + q] = w.pi[q];
             }
         }
         if (k == 0) {   // on a QP failure the previous u_0 stays in force
@@ -183,9 +184,9 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
     //      the whole loop runs inside the kernel, one OCP per group, no host round trip ----
     double pin[3], lamn[8], res[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pin[q] = (on && k < N) ? sk[(R_PI + q) << 6] : 0.0;
+    for (int q = 0; q < 3; ++q) pin[q] = (on && k < N) ? ck[C_PI + q] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? sk[(R_LAM + q) << 6] : 0.0;
+    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? ck[C_LAM + q] : 0.0;
     bool running = inst;
     int sqp_it = 0, qp_it = 0, diag = 0;
     status = 2;   // MAXITER unless a residual check passes
@@ -242,13 +243,13 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
         if (io.u0) { io.u0[2 * i] = ui[0]; io.u0[2 * i + 1] = ui[1]; }
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) sk[(R_X + q) << 6] = xi[q];
+    for (int q = 0; q < 3; ++q) ck[C_X + q] = xi[q];
     if (k < N) {
-        sk[(R_U + 0) << 6] = ui[0]; sk[(R_U + 1) << 6] = ui[1];
+        ck[C_U + 0] = ui[0]; ck[C_U + 1] = ui[1];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sk[(R_PI + q) << 6] = pin[q];
+        for (int q = 0; q < 3; ++q) ck[C_PI + q] = pin[q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sk[(R_LAM + q) << 6] = lamn[q];
+        for (int q = 0; q < 8; ++q) ck[C_LAM + q] = lamn[q];
     }
 }
 
@@ -368,12 +369,50 @@ __global__ __launch_bounds__(256) void k_unpack(double* __restrict__ dst, int ns
     }
 }
 
+// AoS capsule <-> C-ABI AoS arrays: src/dst [B][nst*ncomp] <-> cap[i][kfirst+s][slot+q].
+__global__ void k_cap_pack(const double* __restrict__ src, int nst, int ncomp, int kfirst, int slot, Mem m, int N, int B) {
+    const size_t R = (size_t)nst * ncomp;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * R) return;
+    const size_t i = idx / R, r = idx - i * R;
+    const int st = (int)(r / ncomp), q = (int)(r - (size_t)st * ncomp);
+    m.cap[(i * (N + 1) + kfirst + st) * MPC_CAP + slot + q] = src[idx];
+}
+__global__ void k_cap_unpack(double* __restrict__ dst, int nst, int ncomp, int kfirst, int slot, Mem m, int N, int B) {
+    const size_t R = (size_t)nst * ncomp;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * R) return;
+    const size_t i = idx / R, r = idx - i * R;
+    const int st = (int)(r / ncomp), q = (int)(r - (size_t)st * ncomp);
+    dst[idx] = m.cap[(i * (N + 1) + kfirst + st) * MPC_CAP + slot + q];
+}
+// Capsule <-> the workspace rows R_X, R_U, R_PI, R_LAM of the lane-per-OCP kernels (only when a
+// handle that owns a capsule is driven through MPC_MODEL_LANE).  One thread per (instance, stage).
+__global__ void k_cap_slab(Mem m, int N, int B, int to_slab) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * (N + 1)) return;
+    const size_t i = idx / (N + 1);
+    const int k = (int)(idx - i * (N + 1));
+    double* cl = m.cap + idx * MPC_CAP;
+    double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63) + ((size_t)(k * MPC_RPS) << 6);
+    if (to_slab) {
+        for (int r = 0; r < 8; ++r) blk[(size_t)r << 6] = cl[r];
+        for (int r = 0; r < 8; ++r) blk[(size_t)(R_LAM + r) << 6] = cl[C_LAM + r];
+    } else {
+        for (int r = 0; r < 8; ++r) cl[r] = blk[(size_t)r << 6];
+        for (int r = 0; r < 8; ++r) cl[C_LAM + r] = blk[(size_t)(R_LAM + r) << 6];
+    }
+}
+
 // H14: zero x, u, pi of the selected capsules (mobile_robot_acados_reset, :830-869).
 __global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)cap) return;
     if (mask && !mask[i]) return;
     double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63);
+    if (m.cap)
+        for (int k = 0; k <= N; ++k)
+            for (int r = 0; r < MPC_CAP; ++r) m.cap[(i * (N + 1) + k) * MPC_CAP + r] = 0.0;
     for (int k = 0; k <= N; ++k)
     {
         for (int r = 0; r < R_YREF; ++r)  // rows R_X, R_U, R_PI are the first 8 of a stage
@@ -509,6 +548,7 @@ struct Shard {
     int sqp_rounds = 0;  // QP rounds of the last full-SQP solve
     char* slab = nullptr;    // primary workspace: capsules (home), inputs, phase 0
     char* slab2 = nullptr;   // secondary workspace for compacted stragglers (lazily sized)
+    double* capbuf = nullptr;  // AoS capsule of the wave model (N <= 63), see Mem::cap
     int* islab = nullptr;
     int* phase_ints = nullptr;  // [MPC_MAX_PHASES] live counts, then [S] flags
     Mem mem, mem2;
@@ -551,6 +591,7 @@ static void free_shard(Shard& s) {
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
+    (void)hipFree(s.capbuf);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
     if (s.z_in) (void)hipHostFree(s.z_in);
@@ -564,6 +605,23 @@ static void free_shard(Shard& s) {
 }
 
 static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
+// iterate rows (x, u, pi) live in the AoS capsule when the shard has one, else in the slab
+static void pack_iter(const Mem& m, int N, hipStream_t st, const double* src, int nst, int ncomp, int row, int n) {
+    if (m.cap) {
+        const size_t tot = (size_t)n * nst * ncomp;
+        hipLaunchKernelGGL(k_cap_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, nst, ncomp, 0, row, m, N, n);
+    } else {
+        hipLaunchKernelGGL(k_pack, tgrid(nst * ncomp, n), dim3(32, 8), 0, st, src, nst, ncomp, 0, row, m, n);
+    }
+}
+static void unpack_iter(const Mem& m, int N, hipStream_t st, double* dst, int nst, int ncomp, int row, int n) {
+    if (m.cap) {
+        const size_t tot = (size_t)n * nst * ncomp;
+        hipLaunchKernelGGL(k_cap_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dst, nst, ncomp, 0, row, m, N, n);
+    } else {
+        hipLaunchKernelGGL(k_unpack, tgrid(nst * ncomp, n), dim3(32, 8), 0, st, dst, nst, ncomp, 0, row, m, n);
+    }
+}
 struct WaveIO;
 static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO* io = nullptr);
 static int pick_model(const mpc_batch* h);
@@ -582,8 +640,8 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
         hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
         hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
     }
-    if (d_xt) hipLaunchKernelGGL(k_pack, tgrid(3 * (N + 1), n), tb, 0, st, (const double*)d_xt, N + 1, 3, 0, (int)R_X, m, n);
-    if (d_ut) hipLaunchKernelGGL(k_pack, tgrid(2 * N, n), tb, 0, st, (const double*)d_ut, N, 2, 0, (int)R_U, m, n);
+    if (d_xt) pack_iter(m, N, st, d_xt, N + 1, 3, (int)R_X, n);
+    if (d_ut) pack_iter(m, N, st, d_ut, N, 2, (int)R_U, n);
     WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
     int rc = enqueue_core(h, s, n, st, wave ? &io : nullptr);
     if (rc != 0) return rc;
@@ -591,8 +649,8 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
         d_u0 = nullptr; d_status = nullptr; d_iter = nullptr;
     }
     if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
-    if (d_xt) hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, st, d_xt, N + 1, 3, 0, (int)R_X, m, n);
-    if (d_ut) hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, st, d_ut, N, 2, 0, (int)R_U, m, n);
+    if (d_xt) unpack_iter(m, N, st, d_xt, N + 1, 3, (int)R_X, n);
+    if (d_ut) unpack_iter(m, N, st, d_ut, N, 2, (int)R_U, n);
     if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
     if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipGetLastError());
@@ -649,6 +707,8 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
         HIPCHK(h, hipGetLastError());
         return 0;
     }
+    const unsigned cgrid = (unsigned)(((size_t)n * (N + 1) + 255) / 256);
+    if (m.cap) hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
     for (int it = 0; it < iters; ++it) {
         if (sqp) {
             // head of an SQP iteration; the host reads the number of instances still iterating
@@ -694,6 +754,7 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
             s.n_ph = 1;
         }
     }
+    if (m.cap) hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 0);   // workspace rows -> capsule
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -776,12 +837,19 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
             HIPCHK(h, hipMemsetAsync(s.islab, 0, islab_ints_for((size_t)capa) * sizeof(int), s.stream));
             s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
+            if (N + 1 <= MPC_WAVE) {
+                const size_t cb = cap_doubles_for(N, (size_t)capa) * sizeof(double);
+                HIPCHK(h, hipMalloc(&s.capbuf, cb));
+                HIPCHK(h, hipMemsetAsync(s.capbuf, 0, cb, s.stream));
+                s.mem.cap = s.capbuf;
+            }
             if (capa > MPC_SINGLE_PHASE_MAX) {
                 // compaction only ever moves instances that are still iterating after a wave
                 // dropped below half occupancy, but size for the worst case
                 HIPCHK(h, hipMalloc(&s.slab2, nbytes));
                 HIPCHK(h, hipMemsetAsync(s.slab2, 0, nbytes, s.stream));
                 s.mem2 = make_mem(s.slab2, s.islab, (size_t)capa, N);
+                s.mem2.cap = s.capbuf;
             }
             HIPCHK(h, hipMalloc(&s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int)));
             HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), s.stream));
@@ -941,7 +1009,7 @@ int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
 int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* pi) {
     if (!h || B < 1 || B > h->capacity) return -1;
     const int N = h->spec.N;
-    const dim3 tb(32, 8);
+
     int prev = 0;
     (void)hipGetDevice(&prev);
     for (Shard& s : h->shards) {
@@ -950,15 +1018,15 @@ int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* p
         const size_t o = (size_t)s.first;
         HIPCHK(h, hipSetDevice(s.device));
         if (xtraj) {
-            hipLaunchKernelGGL(k_unpack, tgrid(3 * (N + 1), n), tb, 0, s.stream, s.s_xt, N + 1, 3, 0, (int)R_X, s.mem, n);
+            unpack_iter(s.mem, N, s.stream, s.s_xt, N + 1, 3, (int)R_X, n);
             HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
         }
         if (utraj) {
-            hipLaunchKernelGGL(k_unpack, tgrid(2 * N, n), tb, 0, s.stream, s.s_ut, N, 2, 0, (int)R_U, s.mem, n);
+            unpack_iter(s.mem, N, s.stream, s.s_ut, N, 2, (int)R_U, n);
             HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
         }
         if (pi) {
-            hipLaunchKernelGGL(k_unpack, tgrid(3 * N, n), tb, 0, s.stream, s.s_pi, N, 3, 0, (int)R_PI, s.mem, n);
+            unpack_iter(s.mem, N, s.stream, s.s_pi, N, 3, (int)R_PI, n);
             HIPCHK(h, hipMemcpyAsync(pi + 3 * N * o, s.s_pi, sizeof(double) * 3 * N * n, hipMemcpyDeviceToHost, s.stream));
         }
         HIPCHK(h, hipGetLastError());

@@ -89,7 +89,12 @@ struct Mem {
     int *STATUS, *QPITER, *DIAG;   // [S] each
     int *SQPITER, *ACTIVE;         // [S] each, full SQP only: QPs solved so far, still iterating
     double* NLPRES;                // [S][4] last NLP residuals (stat, eq, ineq, comp), full SQP only
+    // AoS capsule of the wave model (null: the iterate lives in the slab rows R_X, R_U, R_PI):
+    // cap[instance][stage 0..N][MPC_CAP] = x 3, u 2, pi 3, lam 8 — lane k of a wavefront reads
+    // and writes one contiguous 64-B line (x, u, pi), fully coalesced across the wave.
+    double* cap;
 };
+enum : int { MPC_CAP = 16, C_X = 0, C_U = 3, C_PI = 5, C_LAM = 8 };
 
 #define MPC_DIAG_ITREF 1  /* HPIPM's corrector refinement test would have asked for a solve */
 #define MPC_DIAG_LQ 2     /* HPIPM's lq_fact=1 test would have switched to the LQ factorisation */
