@@ -707,6 +707,15 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
         HIPCHK(h, hipGetLastError());
         return 0;
     }
+    if (n > MPC_SINGLE_PHASE_MAX && !s.slab2) {
+        // second workspace for the compacted stragglers of the phased solve, allocated on the
+        // first large lane-model solve (handles that only ever run the wave model never pay for it)
+        const size_t nbytes = slab_bytes_for(N, (size_t)(s.cap > 0 ? s.cap : 1));
+        HIPCHK(h, hipMalloc(&s.slab2, nbytes));
+        HIPCHK(h, hipMemsetAsync(s.slab2, 0, nbytes, st));
+        s.mem2 = make_mem(s.slab2, s.islab, (size_t)(s.cap > 0 ? s.cap : 1), N);
+        s.mem2.cap = s.capbuf;
+    }
     const unsigned cgrid = (unsigned)(((size_t)n * (N + 1) + 255) / 256);
     if (m.cap) hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
     for (int it = 0; it < iters; ++it) {
@@ -842,14 +851,6 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
                 HIPCHK(h, hipMalloc(&s.capbuf, cb));
                 HIPCHK(h, hipMemsetAsync(s.capbuf, 0, cb, s.stream));
                 s.mem.cap = s.capbuf;
-            }
-            if (capa > MPC_SINGLE_PHASE_MAX) {
-                // compaction only ever moves instances that are still iterating after a wave
-                // dropped below half occupancy, but size for the worst case
-                HIPCHK(h, hipMalloc(&s.slab2, nbytes));
-                HIPCHK(h, hipMemsetAsync(s.slab2, 0, nbytes, s.stream));
-                s.mem2 = make_mem(s.slab2, s.islab, (size_t)capa, N);
-                s.mem2.cap = s.capbuf;
             }
             HIPCHK(h, hipMalloc(&s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int)));
             HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), s.stream));
