@@ -157,6 +157,18 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
  * sqp_iter [B], res4 [B][4]. */
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 
+/* Per-instance diagnostic bits of the last solve (host pointer diag [B]); 0 on every workload the
+ * tests measure.  No counterpart in the reference: they record where this solver's arithmetic
+ * would have left HPIPM's path (deviations).
+ *   1  HPIPM's corrector iterative refinement would have run (not performed here)
+ *   2  HPIPM's lq_fact = 1 switch to the LQ factorisation would have fired (not performed here)
+ *   4  wave model: a parallel Riccati scan failed its a-posteriori check against the Riccati
+ *      equation and that factorisation was redone with the sequential recursion */
+#define MPC_DIAG_ITREF 1
+#define MPC_DIAG_LQ 2
+#define MPC_DIAG_SCAN_FALLBACK 4
+int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
+
 /* Execution model of the solve kernels (no counterpart in the reference; results agree to
  * rounding, ~1e-13, across models).  AUTO = WAVE when it applies, else LANE.
  *   LANE     one OCP per lane, IPM workspace in HBM (any N <= MPC_MAX_N, full SQP);

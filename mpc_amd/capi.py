@@ -25,7 +25,7 @@ EXPORTS = (
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
-    "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model",
+    "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model", "mpc_batch_get_diag",
 )
 
 
@@ -83,6 +83,7 @@ def lib():
     L.mpc_batch_track_init.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]
     L.mpc_batch_track_run.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip]
     L.mpc_batch_set_model.argtypes = [_vp, ctypes.c_int]
+    L.mpc_batch_get_diag.argtypes = [_vp, ctypes.c_int, _ip]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -196,6 +197,13 @@ class BatchSolver:
         target, status = np.zeros(B, np.int32), np.zeros(B, np.int32)
         self._check(lib().mpc_batch_track_run(self._h, B, n_ticks, _p(x), _p(u), _pi(target), _pi(status)), "mpc_batch_track_run")
         return dict(x=x, u=u, target=target, status=status)
+
+    def get_diag(self, B=None):
+        """Per-instance diagnostic bits of the last solve (MPC_DIAG_* in include/mpc_batch.h)."""
+        B = self.capacity if B is None else B
+        d = np.zeros(B, np.int32)
+        self._check(lib().mpc_batch_get_diag(self._h, B, _pi(d)), "mpc_batch_get_diag")
+        return d
 
     MODELS = {"auto": 0, "lane": 1, "wave": 2, "waveseq": 3}
 

@@ -3,6 +3,7 @@
 // d_ocp_qp_ipm_arg_set_default(mode) and acados' qp_iter_max override (:670-682).
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mpc_batch.h"
@@ -66,6 +67,8 @@ inline Consts make_consts(const mpc_ocp_spec_t& s) {
     c.lq_tol = 1e-5;
     c.sqp = s.sqp_max_iter > 1 ? 1 : 0;
     c.nlp_tol = s.nlp_tol;
+    c.scan_tol_P = getenv("MPC_SCAN_TOL_P") ? atof(getenv("MPC_SCAN_TOL_P")) : 1e-11;
+    c.scan_tol_lin = getenv("MPC_SCAN_TOL_LIN") ? atof(getenv("MPC_SCAN_TOL_LIN")) : 1e-8;
     return c;
 }
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
         }
         if (!on) return;
         if (k == 0) {
-            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag; m.STATUS[i] = status;
+            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag; m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
             if (io.qp_iter) io.qp_iter[i] = s.kk;
             if (io.u0) { io.u0[2 * i] = ok ? ui[0] : u_prev0; io.u0[2 * i + 1] = ok ? ui[1] : u_prev1; }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
     }
     if (!on) return;
     if (k == 0) {
-        m.QPITER[i] = qp_it; m.DIAG[i] = diag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
+        m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
         sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];
@@ -1172,6 +1172,21 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
         }
     }
     h->last_ms = worst;
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag) {
+    if (!h || B < 1 || B > h->capacity || !diag) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        HIPCHK(h, hipMemcpy(diag + s.first, s.mem.DIAG, sizeof(int) * n, hipMemcpyDeviceToHost));
+    }
     (void)hipSetDevice(prev);
     return 0;
 }

@@ -51,6 +51,9 @@ struct Consts {
     double lq_tol;        // lin-system residual above which HPIPM would switch to LQ (diagnostic)
     int sqp;              // 1: full SQP (sqp_max_iter > 1) — k_nlp_res linearises and gates the instances
     double nlp_tol;       // exit tolerance on the four NLP residuals (full SQP only)
+    // wave model, acceptance tests of the parallel scans (fallback to the sequential recursion):
+    double scan_tol_P;    // relative residual of the Riccati equation, stage by stage
+    double scan_tol_lin;  // stationarity residual of the corrector's linear system (absolute)
 };
 
 // Workspace layout.  One contiguous block per wavefront (64 instances):
@@ -96,8 +99,7 @@ struct Mem {
 };
 enum : int { MPC_CAP = 16, C_X = 0, C_U = 3, C_PI = 5, C_LAM = 8 };
 
-#define MPC_DIAG_ITREF 1  /* HPIPM's corrector refinement test would have asked for a solve */
-#define MPC_DIAG_LQ 2     /* HPIPM's lq_fact=1 test would have switched to the LQ factorisation */
+// MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK: include/mpc_batch.h
 
 // ------------------------------------------------------------------------------------
 // Per-stage algebra shared by the two execution models (one OCP per lane: Lane below; one OCP

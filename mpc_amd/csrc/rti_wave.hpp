@@ -101,6 +101,8 @@ struct Wave : Algebra {
     double id0, l10, id1, K00, K01, K02, K10, K11, K12;
     double dza[4], dz[5], dpi[3];
     double ti[8];                // 1 / t of the current slacks (same bits as recomputing it in every pass)
+    int wdiag = 0;               // MPC_DIAG_* bits raised inside the sweeps
+    bool seq_now = false;        // SCAN build: use the sequential recursions (fallback of one iteration)
 
     struct State {
         int kk, diag;
@@ -289,8 +291,22 @@ struct Wave : Algebra {
         n.m = group_reduce<GW>(pm, OpMax());
         n.musum = group_reduce<GW>(ps, OpSum());
 
-        if (SCAN) factor_scan(Gam, gam);
-        else factor_seq(Gam, gam);
+        factor(Gam, gam);
+    }
+
+    __device__ __forceinline__ void factor(const double Gam[4], const double gam[4]) {
+        if (SCAN && !seq_now) {
+            // The scan re-associates the recursion; with strongly active STATE bounds (J ~ 1e8,
+            // I + C J ill-conditioned) it can lose digits the sequential recursion keeps.  The
+            // guard is the acceptance test on the linear system's residual in iterate(); the
+            // optional stage-wise Riccati check (MPC_SCAN_CHECK_P) falls back right here.
+            if (!factor_scan(Gam, gam)) {
+                wdiag |= MPC_DIAG_SCAN_FALLBACK;
+                factor_seq(Gam, gam);
+            }
+        } else {
+            factor_seq(Gam, gam);
+        }
     }
 
     // --- Riccati factorisation + affine right-hand side, stage N-1 down to 0: the lane that
@@ -412,7 +428,7 @@ struct Wave : Algebra {
         return F;
     }
 
-    __device__ __forceinline__ void factor_scan(const double Gam[4], const double gam[4]) {
+    __device__ __forceinline__ bool factor_scan(const double Gam[4], const double gam[4]) {
         // --- elements ---
         M3 A;
         double C[6], J[6];   // symmetric: 00, 10, 11, 20, 21, 22
@@ -501,11 +517,35 @@ struct Wave : Algebra {
         const bool kk = mid && !is0;
         K00 = kk ? g.K00 : 0.0; K01 = kk ? g.K01 : 0.0; K02 = kk ? g.K02 : 0.0;
         K10 = kk ? g.K10 : 0.0; K11 = kk ? g.K11 : 0.0; K12 = kk ? g.K12 : 0.0;
+        // --- a-posteriori check: P_k of the scan against one sequential Riccati step from P_{k+1} ---
+        // Off by default: the lin_g acceptance test in iterate() subsumes it (an inaccurate P shows up
+        // as a stationarity residual of the linear system) and it costs 3.5 % of the kernel.
+#ifdef MPC_SCAN_CHECK_P
+        {
+            const double a = ab.a, b = ab.b;
+            const double S02 = P.p00 * a + P.p10 * b + P.p20;
+            const double S12 = P.p10 * a + P.p11 * b + P.p21;
+            const double S22 = P.p20 * a + P.p21 * b + P.p22;
+            const double Q00 = ((c.wg[2] + c.reg_prim) + Gam[2] + P.p00) + (g.M00 * g.K00 + g.M10 * g.K10);
+            const double Q10 = P.p10 + (g.M01 * g.K00 + g.M11 * g.K10);
+            const double Q11 = ((c.wg[3] + c.reg_prim) + Gam[3] + P.p11) + (g.M01 * g.K01 + g.M11 * g.K11);
+            const double Q20 = (a * P.p00 + b * P.p10 + P.p20) + (g.X02 * g.K00 + g.X12 * g.K10);
+            const double Q21 = (a * P.p10 + b * P.p11 + P.p21) + (g.X02 * g.K01 + g.X12 * g.K11);
+            const double Q22 = ((c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22)) + (g.X02 * g.K02 + g.X12 * g.K12);
+            double err = fmax(fmax(fabs(Q00 - J[0]), fabs(Q10 - J[1])), fmax(fabs(Q11 - J[2]), fabs(Q20 - J[3])));
+            err = fmax(err, fmax(fabs(Q21 - J[4]), fabs(Q22 - J[5])));
+            const double scale = fmax(fmax(fabs(J[0]), fabs(J[2])), fabs(J[5]));
+            double bad = (kk && !(err <= c.scan_tol_P * scale)) ? 1.0 : 0.0;   // NaN counts as bad
+            bad = group_reduce<GW>(bad, OpMax());
+            if (bad != 0.0) return false;
+        }
+#endif
         // --- affine right-hand side ---
         const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
         const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
         const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
         rhs_scan(rg[0] + gam[0], rg[1] + gam[1], rg[2] + gam[2], rg[3] + gam[3], q0, q1, q2);
+        return true;
     }
 
     // p_k = (hxp + K^T hup) + Phi^T (q + p_{k+1}),  kff = -(Huu)^-1 (hup + B^T (q + p_{k+1}))
@@ -571,7 +611,7 @@ struct Wave : Algebra {
         const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
         const double hup0 = rg[0] + gam[0], hup1 = rg[1] + gam[1];
         const double hxp0 = rg[2] + gam[2], hxp1 = rg[3] + gam[3];
-        if (SCAN) rhs_scan(hup0, hup1, hxp0, hxp1, q0, q1, q2);
+        if (SCAN && !seq_now) rhs_scan(hup0, hup1, hxp0, hxp1, q0, q1, q2);
         else rhs_seq(hup0, hup1, hxp0, hxp1, q0, q1, q2);
     }
 
@@ -627,7 +667,7 @@ struct Wave : Algebra {
     __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o) {
         double nx0 = 0.0, nx1 = 0.0, nx2 = 0.0;   // dx_{k+1}, produced by the lane of stage k
         double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (SCAN) fwd_scan(nx0, nx1, nx2, dl);
+        if (SCAN && !seq_now) fwd_scan(nx0, nx1, nx2, dl);
         else fwd_seq(nx0, nx1, nx2, dl);
         double pn = 1.0, pd = -1.0, dn = 1.0, dd = -1.0;   // step-length candidates as ratios n / d = -1
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
@@ -708,31 +748,60 @@ struct Wave : Algebra {
                (s.n.g > c.res_g_max || s.n.b > c.res_b_max || s.n.d > c.res_d_max ||
                 fabs(s.n.m - c.tau_min) > c.res_m_max);
     }
+    // Barrier terms of the current point (what BU hands to the factorisation), recomputed for the
+    // sequential redo of an iteration.
+    __device__ __forceinline__ void refactor_seq() {
+        double Gam[4], gam[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Con q;
+            con_cached(j, q);
+            const bool hb = has_bound(j);
+            Gam[j] = hb ? con_Gamma(q) : 0.0;
+            gam[j] = hb ? con_gamma(q) : 0.0;
+        }
+        factor_seq(Gam, gam);
+    }
+
     __device__ __forceinline__ void iterate(State& s) {
         const double nci = nc_inv();
-        FwdOut fa;
-        fw<false>(0, 0.0, fa);
-        const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
-        const double mu_aff0 = (s.n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
-        const double tmp = mu_aff0 / s.mu;
-        const double sigma = tmp * tmp * tmp;
-        double sigma_mu = sigma * s.mu;
-        if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
-        // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
-        // (mode 2).  A loop instead of two inlined copies (code size).
         int mode = 1;
         FwdOut fc;
-        double alpha = 0.0;
+        double alpha = 0.0, sigma_mu = 0.0;
+        // The search direction.  SCAN build: the stationarity residual of the linear system
+        // (lin_g, what HPIPM's refinement loop tests against 1e-6) is checked against 1e-8; if the
+        // scans were not accurate enough (strongly active state bounds), the iteration is redone
+        // once with the sequential recursions.  A loop, not two inlined copies (code size).
 #pragma nounroll
-        for (;;) {
-            bw(mode, sigma_mu);
-            fw<true>(mode, sigma_mu, fc);
-            alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
-            if (mode == 2) break;
-            const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
-            if (!(mu_aff1 > 2.0 * mu_aff0)) break;
-            mode = 2;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (attempt == 1) {
+                wdiag |= MPC_DIAG_SCAN_FALLBACK;
+                seq_now = true;
+                refactor_seq();
+            }
+            FwdOut fa;
+            fw<false>(0, 0.0, fa);
+            const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
+            const double mu_aff0 = (s.n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
+            const double tmp = mu_aff0 / s.mu;
+            const double sigma = tmp * tmp * tmp;
+            sigma_mu = sigma * s.mu;
+            if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+            // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
+            mode = 1;
+#pragma nounroll
+            for (;;) {
+                bw(mode, sigma_mu);
+                fw<true>(mode, sigma_mu, fc);
+                alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
+                if (mode == 2) break;
+                const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
+                if (!(mu_aff1 > 2.0 * mu_aff0)) break;
+                mode = 2;
+            }
+            if (!SCAN || attempt == 1 || fc.lin_g < c.scan_tol_lin) break;
         }
+        seq_now = false;
         if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF;
         if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
