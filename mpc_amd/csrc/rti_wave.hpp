@@ -58,8 +58,13 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
     return v;
 }
 // lane i <- lane i+d / lane i-d for any d (ds_bpermute; out-of-range lanes return their own value)
+#ifdef MPC_AB_NO_DPP1
+__device__ __forceinline__ double lane_down(double v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ double lane_up(double v, int d) { return __shfl_up(v, d, 64); }
+#else
 __device__ __forceinline__ double lane_down(double v, int d) { return d == 1 ? lane_next(v, v) : __shfl_down(v, d, 64); }
 __device__ __forceinline__ double lane_up(double v, int d) { return d == 1 ? lane_prev(v, v) : __shfl_up(v, d, 64); }
+#endif
 
 // dense 3x3 helpers for the parallel scans (row-major)
 struct M3 { double m[9]; };
@@ -122,8 +127,13 @@ struct Wave : Algebra {
         q.rd_u = q.t_u + z[j] - c.ub[j];
         q.rm_l = q.lam_l * q.t_l;
         q.rm_u = q.lam_u * q.t_u;
+#ifdef MPC_AB_NO_TI_CACHE
+        q.ti_l = rcp(q.t_l);
+        q.ti_u = rcp(q.t_u);
+#else
         q.ti_l = ti[j];
         q.ti_u = ti[4 + j];
+#endif
     }
 
     // ERK4 linearisation + OCP_QP_INIT_VAR cold start of this stage (Lane::prepare)

@@ -527,3 +527,31 @@ def test_diag_is_clean_on_the_bench_workload():
         r = s.solve(x0, yref, yref_e)
         assert (r["status"] == 0).all() and (s.get_diag(B) == 0).all(), t
     s.close()
+
+
+def test_device_closed_loop_past_the_end_of_the_path(oracle):
+    """mpc_batch_track_* where the window runs off the end of the path (hold the last waypoint,
+    zero input references, src/optimizer.cpp:255-261) and the target index saturates."""
+    import os
+    from mpc_amd.optimizer import Optimizer, load_txt
+    from tests.oracle_solver import OracleSolver
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))[:120]
+    u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))[:121]
+    B, T, v_ref = 8, 0.1, 0.5
+    start = np.tile(s[60], (B, 1)) + np.linspace(-0.03, 0.03, B)[:, None] * np.array([1.0, 1.0, 0.5])
+    opts = [Optimizer(T, 40, v_ref, *start[i], state_refs=s, input_refs=u, solver_factory=OracleSolver) for i in range(B)]
+    solver = capi.BatchSolver(opts[0].spec, B)
+    solver.track_set_path(s, u)
+    solver.track_init(start, T, v_ref)
+    for k in range(70):
+        r = solver.track_run(1)
+        for i, o in enumerate(opts):
+            o.update_and_solve(o.x_current)
+            o.integrate_next_states()
+            assert o.target_waypoint_index == r["target"][i], (k, i)
+        uo = np.array([o.u_current for o in opts]); xo = np.array([o.x_current for o in opts])
+        assert np.abs(uo - r["u"]).max() < TOL_HARD and np.abs(xo - r["x"]).max() < TOL_HARD, k
+    assert (r["target"] >= len(s) - 6).all()          # the window hangs over the end: held waypoints, zero input refs
+    assert np.abs(r["u"][:, 0]).max() < 0.2            # and the vehicles are braking towards it
+    solver.close()
