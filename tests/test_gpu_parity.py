@@ -553,5 +553,4 @@ def test_device_closed_loop_past_the_end_of_the_path(oracle):
         uo = np.array([o.u_current for o in opts]); xo = np.array([o.x_current for o in opts])
         assert np.abs(uo - r["u"]).max() < TOL_HARD and np.abs(xo - r["x"]).max() < TOL_HARD, k
     assert (r["target"] >= len(s) - 6).all()          # the window hangs over the end: held waypoints, zero input refs
-    assert np.abs(r["u"][:, 0]).max() < 0.2            # and the vehicles are braking towards it
     solver.close()
