@@ -173,7 +173,8 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
  * rounding, ~1e-13, across models).  AUTO = WAVE when it applies, else LANE.
  *   LANE     one OCP per lane, IPM workspace in HBM (any N <= MPC_MAX_N, full SQP);
  *   WAVE     one OCP per wavefront (lane = stage), workspace in registers, Riccati recursion
- *            and the two substitutions as parallel scans (N <= 63, SQP_RTI only);
+ *            and the two substitutions as parallel scans (N <= 127; 64 <= N uses a 128-thread
+ *            workgroup per OCP);
  *   WAVE_SEQ same mapping with sequential recursions (cross-check of the scans).
  * A model that does not apply to the handle's spec falls back to LANE.  The environment
  * variable MPC_MODEL=lane|wave|waveseq sets the default of handles left on AUTO. */

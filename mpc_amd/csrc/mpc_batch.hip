@@ -85,6 +85,14 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // instance's workspace column and writes the new iterate, u0, status back to it; nothing else
 // touches memory.  Every lane of the wave runs the whole kernel (DPP shifts and reductions need
 // the full wave); a group whose instance has converged is masked by `go`.
+// cross-lane policy of this thread (rti_wave.hpp): registers/DPP for one wavefront, LDS for the
+// two-wavefront workgroup
+template <class X> __device__ __forceinline__ X make_policy(int) { return X(); }
+template <> __device__ __forceinline__ XBlock make_policy<XBlock>(int t) {
+    __shared__ double xb_lds[2 * MPC_XB_MAXN * MPC_XB_LANES];
+    return XBlock(xb_lds, t);
+}
+
 // Optional direct batch I/O of k_wave in the C-ABI's AoS layouts (device pointers, any may be
 // null): inputs are then read straight from the caller's arrays (lane k reads yref[i][k][0..4],
 // coalesced) instead of from packed workspace rows, and u0 / status / qp_iter are written
@@ -98,9 +106,10 @@ struct WaveIO {
     int* qp_iter;          // [B]
 };
 
-template <int GW, bool SCAN, bool SQP>
-__global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
-    constexpr int G = MPC_WAVE / GW;
+template <class X, bool SCAN, bool SQP>
+__global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
+    constexpr int G = X::PER_BLOCK;
+    constexpr int GW = X::LANES;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;
     const size_t i = (size_t)blockIdx.x * G + g;
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
     double* sk = col + ((size_t)(kcl * MPC_RPS) << 6);
     double* sN = col + ((size_t)(N * MPC_RPS) << 6);
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
-    Wave<GW, SCAN> w(c, k);
+    X xpol = make_policy<X>(l);
+    Wave<X, SCAN> w(c, k, xpol);
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
         for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
     }
     const double u_prev0 = ui[0], u_prev1 = ui[1];
-    typename Wave<GW, SCAN>::State s;
+    typename Wave<X, SCAN>::State s;
     s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0;
     s.n.g = s.n.b = s.n.d = s.n.m = s.n.musum = 0.0;
     int status = 0;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
         w.begin(s);
         for (;;) {
             const bool go = inst && w.cont(s);
-            if (!__any(go)) break;
+            if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
         // status (d_ocp_qp_ipm_solve tail + ocp_qp_hpipm + ocp_nlp_sqp_rti mapping)
@@ -201,14 +211,14 @@ __global__ __launch_bounds__(MPC_WAVE, MPC_WAVE_OCC) void k_wave(Consts c, Mem m
                 running = false;
             }
         }
-        if (!__any(running)) break;
+        if (!w.x.any(running)) break;
         if (running) {
             w.cold_start(xi, ui, x0b);
             w.begin(s);
         }
         for (;;) {
             const bool go = running && w.cont(s);
-            if (!__any(go)) break;
+            if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
         if (running) {
@@ -669,7 +679,7 @@ static int pick_model(const mpc_batch* h) {
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
     }
     if (model == MPC_MODEL_AUTO) model = MPC_MODEL_WAVE;
-    if (h->spec.N + 1 > MPC_WAVE) model = MPC_MODEL_LANE;
+    if (h->spec.N + 1 > MPC_XB_LANES) model = MPC_MODEL_LANE;
     return model;
 }
 
@@ -686,21 +696,21 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
         // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
         // the parallel scans (development / cross-check; RTI only)
         const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
-        const dim3 blk(MPC_WAVE);
         const int mi = h->spec.sqp_max_iter;
         WaveIO wio;
         if (io) wio = *io; else memset(&wio, 0, sizeof(wio));
         HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-#define MPC_LAUNCH_WAVE(GW_, PER_)                                                                                        \
+#define MPC_LAUNCH_WAVE(X_)                                                                                               \
         do {                                                                                                              \
-            const dim3 grd((n + (PER_) - 1) / (PER_));                                                                    \
-            if (sqp) hipLaunchKernelGGL((k_wave<GW_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);            \
-            else if (seq) hipLaunchKernelGGL((k_wave<GW_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);     \
-            else hipLaunchKernelGGL((k_wave<GW_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);               \
+            const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                    \
+            if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);             \
+            else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);      \
+            else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);                \
         } while (0)
-        if (N + 1 <= 16) MPC_LAUNCH_WAVE(16, 4);
-        else if (N + 1 <= 32) MPC_LAUNCH_WAVE(32, 2);
-        else MPC_LAUNCH_WAVE(64, 1);
+        if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
+        else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
+        else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
+        else MPC_LAUNCH_WAVE(XBlock);
 #undef MPC_LAUNCH_WAVE
         HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
         s.n_ph = 1;
@@ -846,7 +856,7 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
             HIPCHK(h, hipMemsetAsync(s.islab, 0, islab_ints_for((size_t)capa) * sizeof(int), s.stream));
             s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
-            if (N + 1 <= MPC_WAVE) {
+            if (N + 1 <= MPC_XB_LANES) {
                 const size_t cb = cap_doubles_for(N, (size_t)capa) * sizeof(double);
                 HIPCHK(h, hipMalloc(&s.capbuf, cb));
                 HIPCHK(h, hipMemsetAsync(s.capbuf, 0, cb, s.stream));

@@ -90,8 +90,91 @@ __device__ __forceinline__ M3 m3_map(const M3& a, F f) {
 struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
 struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
 
-template <int GW, bool SCAN>
+// ---- cross-lane policies ---------------------------------------------------------------
+// XWave<GW>: one OCP per GW lanes of a wavefront (GW = 64, 32, 16) — DPP / ds_bpermute.
+template <int GW>
+struct XWave {
+    static constexpr int LANES = GW;       // lanes per OCP
+    static constexpr int THREADS = 64;     // workgroup size
+    static constexpr int PER_BLOCK = 64 / GW;
+    template <int n> __device__ __forceinline__ void next(double (&v)[n]) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = lane_next(v[i]);
+    }
+    template <int n> __device__ __forceinline__ void prev(double (&v)[n]) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = lane_prev(v[i]);
+    }
+    template <int n> __device__ __forceinline__ void down(double (&v)[n], int d) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = lane_down(v[i], d);
+    }
+    template <int n> __device__ __forceinline__ void up(double (&v)[n], int d) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = lane_up(v[i], d);
+    }
+    template <int n> __device__ __forceinline__ void rmax(double (&v)[n]) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = group_reduce<GW>(v[i], OpMax());
+    }
+    template <int n> __device__ __forceinline__ void rsum(double (&v)[n]) const {
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = group_reduce<GW>(v[i], OpSum());
+    }
+    __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+};
+
+// XBlock: one OCP per 128-thread workgroup (two wavefronts, lane = stage for N + 1 <= 128).
+// Values cross the wavefront boundary through LDS: a batch of n values is written to one of two
+// slots, one barrier, neighbours read; alternating slots make the single barrier sufficient (a
+// wavefront can be at most one exchange ahead of the other).
+#define MPC_XB_LANES 128
+#define MPC_XB_MAXN 21
+struct XBlock {
+    static constexpr int LANES = MPC_XB_LANES;
+    static constexpr int THREADS = MPC_XB_LANES;
+    static constexpr int PER_BLOCK = 1;
+    double* lds;        // [2][MPC_XB_MAXN][128]
+    int t;              // threadIdx.x
+    mutable int slot;
+    __device__ __forceinline__ XBlock(double* lds_, int t_) : lds(lds_), t(t_), slot(0) {}
+    template <int n> __device__ __forceinline__ void shift(double (&v)[n], int delta) const {
+        double* b = lds + slot * (MPC_XB_MAXN * MPC_XB_LANES);
+        slot ^= 1;
+#pragma unroll
+        for (int i = 0; i < n; ++i) b[i * MPC_XB_LANES + t] = v[i];
+        __syncthreads();
+        const int src = t + delta;
+        if (src >= 0 && src < MPC_XB_LANES) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) v[i] = b[i * MPC_XB_LANES + src];
+        }
+    }
+    template <int n> __device__ __forceinline__ void next(double (&v)[n]) const { shift(v, 1); }
+    template <int n> __device__ __forceinline__ void prev(double (&v)[n]) const { shift(v, -1); }
+    template <int n> __device__ __forceinline__ void down(double (&v)[n], int d) const { shift(v, d); }
+    template <int n> __device__ __forceinline__ void up(double (&v)[n], int d) const { shift(v, -d); }
+    template <int n, class Op> __device__ __forceinline__ void reduce(double (&v)[n], Op op) const {
+        double* b = lds + slot * (MPC_XB_MAXN * MPC_XB_LANES);
+        slot ^= 1;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            v[i] = group_reduce<64>(v[i], op);
+            if ((t & 63) == 0) b[i * MPC_XB_LANES + (t >> 6)] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < n; ++i) v[i] = op(b[i * MPC_XB_LANES], b[i * MPC_XB_LANES + 1]);
+    }
+    template <int n> __device__ __forceinline__ void rmax(double (&v)[n]) const { reduce(v, OpMax()); }
+    template <int n> __device__ __forceinline__ void rsum(double (&v)[n]) const { reduce(v, OpSum()); }
+    __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
+};
+
+template <class X, bool SCAN>
 struct Wave : Algebra {
+    static constexpr int GW = X::LANES;
+    X x;
     int k, N;                    // stage of this lane, horizon
     bool act, mid, isN, is0;     // k <= N, k < N, k == N, k == 0
     // inputs and linearisation of this stage
@@ -116,7 +199,7 @@ struct Wave : Algebra {
         Norms n;
     };
 
-    __device__ __forceinline__ Wave(const Consts& c_, int stage) : Algebra(c_), k(stage), N(c_.N) {
+    __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_) : Algebra(c_), x(x_), k(stage), N(c_.N) {
         act = k <= N; mid = k < N; isN = k == N; is0 = k == 0;
     }
     __device__ __forceinline__ bool has_bound(int j) const { return mid && (j < 2 || !is0); }
@@ -157,12 +240,15 @@ struct Wave : Algebra {
         double g[5];
         g[0] = c.wg[0] * (zz[0] - yref[3]);
         g[1] = c.wg[1] * (zz[1] - yref[4]);
+        double pmv[3] = {pin[0], pin[1], pin[2]}, xnv[3] = {xi[0], xi[1], xi[2]};
+        x.prev(pmv);
+        x.next(xnv);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            double pm = lane_prev(pin[q]);
+            double pm = pmv[q];
             if (is0) pm = 0.0;
             g[2 + q] = (isN ? c.we[q] : c.wg[2 + q]) * (zz[2 + q] - yref[q]) - pm;
-            const double xnext = lane_next(xi[q]);
+            const double xnext = xnv[q];
             if (mid) r_eq = amax(r_eq, xn[q] - xnext);
             if (is0) r_ineq = amax(r_ineq, x0bar[q] - xi[q]);
         }
@@ -182,10 +268,9 @@ struct Wave : Algebra {
             r_stat = amax(r_stat, g[0]); r_stat = amax(r_stat, g[1]);
         }
         if (act && !is0) { r_stat = amax(r_stat, g[2]); r_stat = amax(r_stat, g[3]); r_stat = amax(r_stat, g[4]); }
-        out[0] = group_reduce<GW>(r_stat, OpMax());
-        out[1] = group_reduce<GW>(r_eq, OpMax());
-        out[2] = group_reduce<GW>(r_ineq, OpMax());
-        out[3] = group_reduce<GW>(r_comp, OpMax());
+        double rr[4] = {r_stat, r_eq, r_ineq, r_comp};
+        x.rmax(rr);
+        out[0] = rr[0]; out[1] = rr[1]; out[2] = rr[2]; out[3] = rr[3];
     }
     __device__ __forceinline__ void cold_start(const double xi[3], const double ui[2], const double x0bar[3]) {
         z[0] = mid ? ui[0] : 0.0;
@@ -254,13 +339,10 @@ struct Wave : Algebra {
             for (int q = 0; q < 3; ++q) pi[q] = pi[q] + alpha * dpi[q];
         }
         // --- residuals at the new point ---
-        double pim[3], zxn[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            pim[q] = lane_prev(pi[q]);
-            if (is0) pim[q] = 0.0;
-            zxn[q] = lane_next(z[2 + q]);
-        }
+        double pim[3] = {pi[0], pi[1], pi[2]}, zxn[3] = {z[2], z[3], z[4]};
+        x.prev(pim);
+        x.next(zxn);
+        if (is0) { pim[0] = pim[1] = pim[2] = 0.0; }
         rg[0] = c.wg[0] * (z[0] - yref[3]);
         rg[1] = c.wg[1] * (z[1] - yref[4]);
 #pragma unroll
@@ -296,11 +378,10 @@ struct Wave : Algebra {
             pg = amax(pg, rg[0]); pg = amax(pg, rg[1]);
         }
         if (act && !is0) { pg = amax(pg, rg[2]); pg = amax(pg, rg[3]); pg = amax(pg, rg[4]); }
-        n.g = group_reduce<GW>(pg, OpMax());
-        n.b = group_reduce<GW>(pb, OpMax());
-        n.d = group_reduce<GW>(pd, OpMax());
-        n.m = group_reduce<GW>(pm, OpMax());
-        n.musum = group_reduce<GW>(ps, OpSum());
+        double nm[4] = {pg, pb, pd, pm}, ns[1] = {ps};
+        x.rmax(nm);
+        x.rsum(ns);
+        n.g = nm[0]; n.b = nm[1]; n.d = nm[2]; n.m = nm[3]; n.musum = ns[0];
 
         factor(Gam, gam);
     }
@@ -328,10 +409,11 @@ struct Wave : Algebra {
         Po.p20 = 0.0; Po.p21 = 0.0; Po.p22 = c.we[2] + c.reg_prim;
         double po0 = rg[2], po1 = rg[3], po2 = rg[4];   // meaningful in lane N
         for (int kc = N - 1; kc >= 0; --kc) {
+            double sh[9] = {Po.p00, Po.p10, Po.p11, Po.p20, Po.p21, Po.p22, po0, po1, po2};
+            x.next(sh);
             Sym3 Pi;
-            Pi.p00 = lane_next(Po.p00); Pi.p10 = lane_next(Po.p10); Pi.p11 = lane_next(Po.p11);
-            Pi.p20 = lane_next(Po.p20); Pi.p21 = lane_next(Po.p21); Pi.p22 = lane_next(Po.p22);
-            const double p0 = lane_next(po0), p1 = lane_next(po1), p2 = lane_next(po2);
+            Pi.p00 = sh[0]; Pi.p10 = sh[1]; Pi.p11 = sh[2]; Pi.p20 = sh[3]; Pi.p21 = sh[4]; Pi.p22 = sh[5];
+            const double p0 = sh[6], p1 = sh[7], p2 = sh[8];
             if (k == kc) {
                 P = Pi;
                 const double w0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2] + p0;
@@ -392,14 +474,10 @@ struct Wave : Algebra {
     __device__ __forceinline__ void affine_suffix_scan(M3& T, double s[3]) const {
 #pragma unroll
         for (int d = 1; d < GW; d *= 2) {
-            M3 T2;
-            double s2[3];
-            if (2 * d < GW) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) T2.m[i] = lane_down(T.m[i], d);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s2[i] = lane_down(s[i], d);
+            M3 T2 = T;
+            double s2[3] = {s[0], s[1], s[2]};
+            if (2 * d < GW) x.down(T2.m, d);
+            x.down(s2, d);
             if (k + d <= N) {
                 double r[3];
                 m3_mulv(T, s2, r);
@@ -413,14 +491,10 @@ struct Wave : Algebra {
     __device__ __forceinline__ void affine_prefix_scan(M3& M, double v[3]) const {
 #pragma unroll
         for (int d = 1; d < GW; d *= 2) {
-            M3 M1;
-            double v1[3];
-            if (2 * d < GW) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M1.m[i] = lane_up(M.m[i], d);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) v1[i] = lane_up(v[i], d);
+            M3 M1 = M;
+            double v1[3] = {v[0], v[1], v[2]};
+            if (2 * d < GW) x.up(M1.m, d);
+            x.up(v1, d);
             if (k >= d && mid) {
                 double r[3];
                 m3_mulv(M, v1, r);
@@ -468,35 +542,43 @@ struct Wave : Algebra {
         for (int d = 1; d < GW; d *= 2) {
             M3 A2;
             double C2[6], J2[6];
-            if (2 * d < GW) {   // the last level only needs J of the right-hand segment
+            if (2 * d < GW) {
+                double e[21];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) A2.m[i] = lane_down(A.m[i], d);
+                for (int i = 0; i < 9; ++i) e[i] = A.m[i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) C2[i] = lane_down(C[i], d);
+                for (int i = 0; i < 6; ++i) { e[9 + i] = C[i]; e[15 + i] = J[i]; }
+                x.down(e, d);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) A2.m[i] = e[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { C2[i] = e[9 + i]; J2[i] = e[15 + i]; }
+            } else {   // the last level only needs J of the right-hand segment
+#pragma unroll
+                for (int i = 0; i < 6; ++i) J2[i] = J[i];
+                x.down(J2, d);
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) J2[i] = lane_down(J[i], d);
             if (k + d <= N) {
                 const bool more = 2 * d < GW;   // A and C are only needed by later steps
-                // X = I + C1 J2
+                // Xm = I + C1 J2
                 M3 Cm, Jm;
                 Cm.m[0] = C[0]; Cm.m[1] = C[1]; Cm.m[2] = C[3]; Cm.m[3] = C[1]; Cm.m[4] = C[2]; Cm.m[5] = C[4]; Cm.m[6] = C[3]; Cm.m[7] = C[4]; Cm.m[8] = C[5];
                 Jm.m[0] = J2[0]; Jm.m[1] = J2[1]; Jm.m[2] = J2[3]; Jm.m[3] = J2[1]; Jm.m[4] = J2[2]; Jm.m[5] = J2[4]; Jm.m[6] = J2[3]; Jm.m[7] = J2[4]; Jm.m[8] = J2[5];
-                M3 X = m3_mul(Cm, Jm);
-                X.m[0] += 1.0; X.m[4] += 1.0; X.m[8] += 1.0;
-                // W = X^-1 (adjugate)
+                M3 Xm = m3_mul(Cm, Jm);
+                Xm.m[0] += 1.0; Xm.m[4] += 1.0; Xm.m[8] += 1.0;
+                // W = Xm^-1 (adjugate)
                 M3 W;
-                const double c00 = X.m[4] * X.m[8] - X.m[5] * X.m[7];
-                const double c01 = X.m[5] * X.m[6] - X.m[3] * X.m[8];
-                const double c02 = X.m[3] * X.m[7] - X.m[4] * X.m[6];
-                const double idet = rcp(X.m[0] * c00 + X.m[1] * c01 + X.m[2] * c02);
+                const double c00 = Xm.m[4] * Xm.m[8] - Xm.m[5] * Xm.m[7];
+                const double c01 = Xm.m[5] * Xm.m[6] - Xm.m[3] * Xm.m[8];
+                const double c02 = Xm.m[3] * Xm.m[7] - Xm.m[4] * Xm.m[6];
+                const double idet = rcp(Xm.m[0] * c00 + Xm.m[1] * c01 + Xm.m[2] * c02);
                 W.m[0] = c00 * idet; W.m[3] = c01 * idet; W.m[6] = c02 * idet;
-                W.m[1] = (X.m[2] * X.m[7] - X.m[1] * X.m[8]) * idet;
-                W.m[4] = (X.m[0] * X.m[8] - X.m[2] * X.m[6]) * idet;
-                W.m[7] = (X.m[1] * X.m[6] - X.m[0] * X.m[7]) * idet;
-                W.m[2] = (X.m[1] * X.m[5] - X.m[2] * X.m[4]) * idet;
-                W.m[5] = (X.m[2] * X.m[3] - X.m[0] * X.m[5]) * idet;
-                W.m[8] = (X.m[0] * X.m[4] - X.m[1] * X.m[3]) * idet;
+                W.m[1] = (Xm.m[2] * Xm.m[7] - Xm.m[1] * Xm.m[8]) * idet;
+                W.m[4] = (Xm.m[0] * Xm.m[8] - Xm.m[2] * Xm.m[6]) * idet;
+                W.m[7] = (Xm.m[1] * Xm.m[6] - Xm.m[0] * Xm.m[7]) * idet;
+                W.m[2] = (Xm.m[1] * Xm.m[5] - Xm.m[2] * Xm.m[4]) * idet;
+                W.m[5] = (Xm.m[2] * Xm.m[3] - Xm.m[0] * Xm.m[5]) * idet;
+                W.m[8] = (Xm.m[0] * Xm.m[4] - Xm.m[1] * Xm.m[3]) * idet;
                 // J12 = A1^T (J2 W) A1 + J1
                 const M3 U = m3_mul(m3_mul(Jm, W), A);
                 J[0] += A.m[0] * U.m[0] + A.m[3] * U.m[3] + A.m[6] * U.m[6];
@@ -520,8 +602,11 @@ struct Wave : Algebra {
             }
         }
         // --- P_{k+1} to the lane of stage k, gains per stage ---
-        P.p00 = lane_next(J[0]); P.p10 = lane_next(J[1]); P.p11 = lane_next(J[2]);
-        P.p20 = lane_next(J[3]); P.p21 = lane_next(J[4]); P.p22 = lane_next(J[5]);
+        {
+            double jn[6] = {J[0], J[1], J[2], J[3], J[4], J[5]};
+            x.next(jn);
+            P.p00 = jn[0]; P.p10 = jn[1]; P.p11 = jn[2]; P.p20 = jn[3]; P.p21 = jn[4]; P.p22 = jn[5];
+        }
         Gain g;
         gain(P, ab, Gam[0], Gam[1], true, g);
         id0 = g.id0; l10 = g.l10; id1 = g.id1;
@@ -547,8 +632,9 @@ struct Wave : Algebra {
             err = fmax(err, fmax(fabs(Q21 - J[4]), fabs(Q22 - J[5])));
             const double scale = fmax(fmax(fabs(J[0]), fabs(J[2])), fabs(J[5]));
             double bad = (kk && !(err <= c.scan_tol_P * scale)) ? 1.0 : 0.0;   // NaN counts as bad
-            bad = group_reduce<GW>(bad, OpMax());
-            if (bad != 0.0) return false;
+            double bb[1] = {bad};
+            x.rmax(bb);
+            if (bb[0] != 0.0) return false;
         }
 #endif
         // --- affine right-hand side ---
@@ -578,7 +664,9 @@ struct Wave : Algebra {
             s[0] = rg[2]; s[1] = rg[3]; s[2] = rg[4];   // lane N: p_N
         }
         affine_suffix_scan(T, s);
-        const double p0 = lane_next(s[0]), p1 = lane_next(s[1]), p2 = lane_next(s[2]);
+        double sn[3] = {s[0], s[1], s[2]};
+        x.next(sn);
+        const double p0 = sn[0], p1 = sn[1], p2 = sn[2];
         if (mid) {
             pv[0] = p0; pv[1] = p1; pv[2] = p2;
             const double w0 = q0 + p0, w1 = q1 + p1, w2 = q2 + p2;
@@ -598,7 +686,9 @@ struct Wave : Algebra {
         if (!mid) { v[0] = v[1] = v[2] = 0.0; }
         affine_prefix_scan(M, v);
         nx0 = v[0]; nx1 = v[1]; nx2 = v[2];
-        double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
+        double dxv[3] = {nx0, nx1, nx2};
+        x.prev(dxv);
+        double dx0 = dxv[0], dx1 = dxv[1], dx2 = dxv[2];
         if (is0) { dx0 = dx1 = dx2 = 0.0; }
         if (mid) {
             dl[0] = kff[0] + (K00 * dx0 + K01 * dx1 + K02 * dx2);
@@ -629,7 +719,9 @@ struct Wave : Algebra {
     __device__ __forceinline__ void rhs_seq(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
         double po0 = rg[2], po1 = rg[3], po2 = rg[4];   // meaningful in lane N
         for (int kc = N - 1; kc >= 0; --kc) {
-            const double p0 = lane_next(po0), p1 = lane_next(po1), p2 = lane_next(po2);
+            double sh[3] = {po0, po1, po2};
+            x.next(sh);
+            const double p0 = sh[0], p1 = sh[1], p2 = sh[2];
             if (k == kc) {
                 pv[0] = p0; pv[1] = p1; pv[2] = p2;
                 const double w0 = q0 + p0, w1 = q1 + p1, w2 = q2 + p2;
@@ -650,7 +742,9 @@ struct Wave : Algebra {
 
     __device__ __forceinline__ void fwd_seq(double& nx0, double& nx1, double& nx2, double dl[5]) {
         for (int kc = 0; kc < N; ++kc) {
-            double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
+            double sh[3] = {nx0, nx1, nx2};
+            x.prev(sh);
+            double dx0 = sh[0], dx1 = sh[1], dx2 = sh[2];
             if (k == kc) {
                 double du0 = kff[0], du1 = kff[1];
                 if (kc != 0) {
@@ -666,8 +760,9 @@ struct Wave : Algebra {
             }
         }
         {
-            const double dx0 = lane_prev(nx0), dx1 = lane_prev(nx1), dx2 = lane_prev(nx2);
-            if (isN) { dl[2] = dx0; dl[3] = dx1; dl[4] = dx2; }
+            double sh[3] = {nx0, nx1, nx2};
+            x.prev(sh);
+            if (isN) { dl[2] = sh[0]; dl[3] = sh[1]; dl[4] = sh[2]; }
         }
     }
 
@@ -711,7 +806,9 @@ struct Wave : Algebra {
             const double dp1 = mid ? P.p10 * nx0 + P.p11 * nx1 + P.p21 * nx2 + pv[1] : 0.0;
             const double dp2 = mid ? P.p20 * nx0 + P.p21 * nx1 + P.p22 * nx2 + pv[2] : 0.0;
             dpi[0] = dp0; dpi[1] = dp1; dpi[2] = dp2;
-            const double dpm0 = lane_prev(dp0), dpm1 = lane_prev(dp1), dpm2 = lane_prev(dp2);
+            double dpm[3] = {dp0, dp1, dp2};
+            x.prev(dpm);
+            const double dpm0 = dpm[0], dpm1 = dpm[1], dpm2 = dpm[2];
             if (mid) {
                 const double lg0 = c.wg[0] * dl[0] + rg[0] + dlam_net[0] + (ab.B00 * dp0 + ab.B10 * dp1 + ab.B20 * dp2);
                 const double lg1 = c.wg[1] * dl[1] + rg[1] + dlam_net[1] + (ab.B01 * dp0 + ab.B11 * dp1 + ab.B21 * dp2);
@@ -734,11 +831,11 @@ struct Wave : Algebra {
         }
         // the running values are negative ratios in (-1, 0]: the binding one is the largest
         const double a_prim = pn * rcp(pd), a_dual = dn * rcp(dd);
-        o.a_prim = -group_reduce<GW>(a_prim, OpMax());
-        o.a_dual = -group_reduce<GW>(a_dual, OpMax());
-        o.s1 = group_reduce<GW>(s1, OpSum());
-        o.s2 = group_reduce<GW>(s2, OpSum());
-        o.lin_g = FINAL ? group_reduce<GW>(lin_g, OpMax()) : 0.0;
+        double am[3] = {a_prim, a_dual, lin_g}, as[2] = {s1, s2};
+        x.rmax(am);
+        x.rsum(as);
+        o.a_prim = -am[0]; o.a_dual = -am[1]; o.s1 = as[0]; o.s2 = as[1];
+        o.lin_g = FINAL ? am[2] : 0.0;
     }
 
     // ---- the RTI step (Lane::begin / cont / iterate) ----
