@@ -554,3 +554,34 @@ def test_device_closed_loop_past_the_end_of_the_path(oracle):
         assert np.abs(uo - r["u"]).max() < TOL_HARD and np.abs(xo - r["x"]).max() < TOL_HARD, k
     assert (r["target"] >= len(s) - 6).all()          # the window hangs over the end: held waypoints, zero input refs
     solver.close()
+
+
+@pytest.mark.parametrize("N", [64, 80, 127])
+def test_workgroup_variant_of_the_wave_model(oracle, N):
+    """64 <= N <= 127: one OCP per 128-thread workgroup (XBlock policy: LDS exchange across the two
+    wavefronts).  RTI cold + warm tick and a short full-SQP run, against the oracle."""
+    B = 70
+    sp, wl = workload.make("mobile_robot", B, N=N)
+    s = capi.BatchSolver(sp, B)
+    s.set_model("wave")
+    xo = uo = None
+    for t in range(2):
+        x0, yref, yref_e = wl.tick(t)
+        ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
+        xo, uo = ro["xtraj"], ro["utraj"]
+        rg = s.solve(x0, yref, yref_e)
+        xg, ug, _ = s.get(B, want_pi=False)
+        rg["xtraj"], rg["utraj"] = xg, ug
+        _compare(ro, rg, B, min_same=0.98)
+    s.close()
+    sp2 = sp.copy(sqp_max_iter=6, nlp_tol=1e-5)
+    s2 = capi.BatchSolver(sp2, B)
+    s2.set_model("wave")
+    x0, yref, yref_e = wl.tick(0)
+    ro = oracle.sqp_batch(sp2, x0, yref, yref_e)
+    rg = s2.solve(x0, yref, yref_e)
+    sit, _ = s2.get_sqp(B)
+    _, ug, _ = s2.get(B, want_pi=False)
+    assert np.array_equal(ro["status"], rg["status"]) and np.array_equal(ro["sqp_iter"], sit)
+    assert np.abs(ro["utraj"] - ug).max() < TOL_PATH
+    s2.close()
