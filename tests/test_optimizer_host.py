@@ -178,3 +178,14 @@ def test_park_maneuver_reaches_target():
         n += 1
     assert rc == 2, (rc, n, o.x_current_transformed)
     assert np.sum((o.x_current_transformed - xs[:3]) ** 2) < 0.0025
+
+
+def test_run_reaches_the_end_of_a_short_path():
+    """Optimizer::run (src/optimizer.cpp:177-206): loop until within 0.1 of the final waypoint."""
+    s, u = path150()
+    s, u = s[:90].copy(), u[:91].copy()
+    o = make(path=(s, u))
+    n = o.run(max_ticks=400)
+    assert n < 400
+    assert np.linalg.norm(s[-1] - o.x_current) < 0.1
+    assert abs(o.t0 - n * o.T) < 1e-9
