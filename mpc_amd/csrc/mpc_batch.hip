@@ -1,11 +1,14 @@
 // mpc_batch.hip — libmpc_amd.so: HIP kernels (gfx950) + the C-ABI of include/mpc_batch.h.
 //
-// Execution model: ONE OCP PER LANE.  A 64-lane wavefront advances 64 independent SQP-RTI
-// solves in lock-step; all per-stage data is structure-of-arrays [row][instance] in HBM so
-// every load/store of a wave is one 512-byte coalesced access (layout: rti_core.hpp).  FP64 VALU only — the 2x2 /
-// 3x3 stage blocks are not dense contractions, so no MFMA (BASELINE.json north_star).
-// The per-lane algorithm is rti_core.hpp; this file adds the batch I/O kernels (AoS <-> SoA
-// transposes through LDS), the handle, sharding over devices and the entry points.
+// Two execution models, both FP64 VALU only — the 2x2 / 3x3 stage blocks
+// are not dense contractions, so no MFMA (BASELINE.json north_star):
+//   WAVE (default)  k_wave: one OCP per wavefront (or per 16/32 lanes, or per 128-thread
+//                   workgroup for N >= 64), lane = stage, IPM workspace in registers, Riccati
+//                   recursion and substitutions as parallel scans — rti_wave.hpp;
+//   LANE            k_phase / k_compact: one OCP per lane, workspace slab in HBM, phased solve
+//                   with straggler compaction — rti_core.hpp.
+// This file adds the batch I/O kernels, the full-SQP head (k_nlp_res), the device closed loop
+// (k_track_*), the handle, sharding over devices and the extern "C" entry points.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,9 +24,6 @@ using namespace mpc;
 
 #define MPC_WAVE 64
 #define MPC_MAX_PHASES 8
-#ifndef MPC_WAVE_OCC
-#define MPC_WAVE_OCC 1   /* min waves per SIMD the wave kernel is compiled for */
-#endif
 // Phase schedule: batches up to this size run as one phase (latency path)
 #define MPC_SINGLE_PHASE_MAX 2048
 // Batches up to this size go through pinned host memory that the kernel reads and writes

@@ -12,12 +12,15 @@
 //   * neighbour access (pi_{k-1}, x_{k+1}) is one DPP wave shift;
 //   * norms, mu and the step lengths are wavefront reductions (DPP butterfly inside a row,
 //     ds_bpermute across rows);
-//   * only the two Riccati recursions are sequential: the lane that owns stage k computes
-//     its step under `if (lane == k)`, then P/p (backward) or dx (forward) moves one lane over
-//     by a DPP shift.
-// The arithmetic of every stage is rti_core.hpp's Algebra (same formulas, same order), so the
-// result differs from the lane-per-OCP kernel only by the association of the three wave-wide
-// sums (mu and the two mu_aff sums) — the same class of deviation as kernel vs oracle.
+//   * the Riccati recursion and the two substitutions are parallel scans over the stages
+//     (factor_scan / rhs_scan / fwd_scan below); the sequential forms (lane k computes under
+//     `if (lane == k)`, P/p or dx move one lane over per step) remain as the in-kernel fallback
+//     of the acceptance test and as the WAVE_SEQ cross-check model.
+// The per-stage arithmetic is rti_core.hpp's Algebra (same formulas, same order as the
+// lane-per-OCP kernel); the scans and the wave-wide sums re-associate, which moves the results
+// at the 1e-13 level — the same class of deviation as kernel vs oracle.
+// Cross-lane communication goes through a policy (XWave: DPP / ds_bpermute inside one
+// wavefront; XBlock: LDS exchange across the two wavefronts of a 128-thread workgroup).
 #pragma once
 #include "rti_core.hpp"
 
@@ -58,13 +61,9 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
     return v;
 }
 // lane i <- lane i+d / lane i-d for any d (ds_bpermute; out-of-range lanes return their own value)
-#ifdef MPC_AB_NO_DPP1
-__device__ __forceinline__ double lane_down(double v, int d) { return __shfl_down(v, d, 64); }
-__device__ __forceinline__ double lane_up(double v, int d) { return __shfl_up(v, d, 64); }
-#else
+// (distance 1 through DPP: measured 1.5 % faster than ds_bpermute)
 __device__ __forceinline__ double lane_down(double v, int d) { return d == 1 ? lane_next(v, v) : __shfl_down(v, d, 64); }
 __device__ __forceinline__ double lane_up(double v, int d) { return d == 1 ? lane_prev(v, v) : __shfl_up(v, d, 64); }
-#endif
 
 // dense 3x3 helpers for the parallel scans (row-major)
 struct M3 { double m[9]; };
@@ -210,13 +209,8 @@ struct Wave : Algebra {
         q.rd_u = q.t_u + z[j] - c.ub[j];
         q.rm_l = q.lam_l * q.t_l;
         q.rm_u = q.lam_u * q.t_u;
-#ifdef MPC_AB_NO_TI_CACHE
-        q.ti_l = rcp(q.t_l);
-        q.ti_u = rcp(q.t_u);
-#else
         q.ti_l = ti[j];
         q.ti_u = ti[4 + j];
-#endif
     }
 
     // ERK4 linearisation + OCP_QP_INIT_VAR cold start of this stage (Lane::prepare)
