@@ -143,8 +143,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     }
     const double u_prev0 = ui[0], u_prev1 = ui[1];
     typename Wave<X, SCAN>::State s;
-    s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0;
-    s.n.g = s.n.b = s.n.d = s.n.m = s.n.musum = 0.0;
+    s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0; s.musum = 0.0; s.open = false;
     int status = 0;
     if (!SQP) {
         // ---- SQP_RTI: one linearisation, one QP, full step ----

@@ -120,7 +120,14 @@ struct XWave {
 #pragma unroll
         for (int i = 0; i < n; ++i) v[i] = group_reduce<GW>(v[i], OpSum());
     }
-    __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }
+    __device__ __forceinline__ bool any(bool p) const { return __any(p) != 0; }   // whole wavefront
+    // any lane of THIS lane's group (one ballot instead of a max-reduction)
+    __device__ __forceinline__ bool gany(bool p) const {
+        const unsigned long long b = __ballot(p);
+        if (GW == 64) return b != 0ull;
+        const int g = (int)(threadIdx.x & 63) / GW;
+        return ((b >> (g * GW)) & ((1ull << GW) - 1ull)) != 0ull;
+    }
 };
 
 // XBlock: one OCP per 128-thread workgroup (two wavefronts, lane = stage for N + 1 <= 128).
@@ -168,6 +175,7 @@ struct XBlock {
     template <int n> __device__ __forceinline__ void rmax(double (&v)[n]) const { reduce(v, OpMax()); }
     template <int n> __device__ __forceinline__ void rsum(double (&v)[n]) const { reduce(v, OpSum()); }
     __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
+    __device__ __forceinline__ bool gany(bool p) const { return __syncthreads_or(p) != 0; }
 };
 
 template <class X, bool SCAN>
@@ -195,7 +203,8 @@ struct Wave : Algebra {
     struct State {
         int kk, diag;
         double alpha, mu;
-        Norms n;
+        double musum;   // sum of lam*t over all bounds
+        bool open;      // some residual norm is above its tolerance (the norm part of HPIPM's loop condition)
     };
 
     __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_) : Algebra(c_), x(x_), k(stage), N(c_.N) {
@@ -307,7 +316,7 @@ struct Wave : Algebra {
     // ---- BU: variable update + residuals (all stages at once) + Riccati factorisation with
     //      the affine right-hand side (sequential over stages).  Lane::sweep_bu.
     template <bool FIRST>
-    __device__ __forceinline__ void bu(int mode, double sigma_mu, double alpha, Norms& n) {
+    __device__ __forceinline__ void bu(int mode, double sigma_mu, double alpha, double& musum, bool& open) {
         if (!FIRST) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -372,10 +381,14 @@ struct Wave : Algebra {
             pg = amax(pg, rg[0]); pg = amax(pg, rg[1]);
         }
         if (act && !is0) { pg = amax(pg, rg[2]); pg = amax(pg, rg[3]); pg = amax(pg, rg[4]); }
-        double nm[4] = {pg, pb, pd, pm}, ns[1] = {ps};
-        x.rmax(nm);
+        // HPIPM tests the four inf-norms against their tolerances; "max over lanes > tol" is "any
+        // lane > tol" (|m - tau_min| > tol is monotone in m for m >= tau_min and false below), so
+        // the four max-reductions collapse into one ballot.  Only mu needs a real reduction.
+        open = x.gany(pg > c.res_g_max || pb > c.res_b_max || pd > c.res_d_max ||
+                      fabs(pm - c.tau_min) > c.res_m_max);
+        double ns[1] = {ps};
         x.rsum(ns);
-        n.g = nm[0]; n.b = nm[1]; n.d = nm[2]; n.m = nm[3]; n.musum = ns[0];
+        musum = ns[0];
 
         factor(Gam, gam);
     }
@@ -762,7 +775,10 @@ struct Wave : Algebra {
 
     // ---- FW: forward substitution (sequential), then step lengths and the mu_aff sums on all
     //      stages at once.  Lane::sweep_fw.
-    struct FwdOut { double a_prim, a_dual, s1, s2, lin_g; };
+    struct FwdOut {
+        double alpha, s1, s2;               // min(alpha_prim, alpha_dual), the two mu_aff sums
+        bool lin_itref, lin_lq, lin_scan;   // lin_g >= itref_tol_g / lq_tol / scan_tol_lin (FINAL only)
+    };
     template <bool FINAL>
     __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o) {
         double nx0 = 0.0, nx1 = 0.0, nx2 = 0.0;   // dx_{k+1}, produced by the lane of stage k
@@ -825,11 +841,15 @@ struct Wave : Algebra {
         }
         // the running values are negative ratios in (-1, 0]: the binding one is the largest
         const double a_prim = pn * rcp(pd), a_dual = dn * rcp(dd);
-        double am[3] = {a_prim, a_dual, lin_g}, as[2] = {s1, s2};
+        // HPIPM steps with alpha = min(alpha_prim, alpha_dual): one reduction on max(a_prim, a_dual)
+        double am[1] = {fmax(a_prim, a_dual)}, as[2] = {s1, s2};
         x.rmax(am);
         x.rsum(as);
-        o.a_prim = -am[0]; o.a_dual = -am[1]; o.s1 = as[0]; o.s2 = as[1];
-        o.lin_g = FINAL ? am[2] : 0.0;
+        o.alpha = -am[0]; o.s1 = as[0]; o.s2 = as[1];
+        // the linear system's residual is only ever compared with thresholds: ballots
+        o.lin_itref = FINAL ? x.gany(!(lin_g < c.itref_tol_g)) : false;
+        o.lin_lq = FINAL ? x.gany(!(lin_g < c.lq_tol)) : false;
+        o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
     }
 
     // ---- the RTI step (Lane::begin / cont / iterate) ----
@@ -839,16 +859,14 @@ struct Wave : Algebra {
         // are far above the lam/t clamps), so the first residual + factorisation pass shares the
         // code of the per-iteration one: one copy of the largest block keeps the kernel within
         // the instruction cache
-        bu<false>(0, 0.0, 0.0, s.n);
-        s.mu = s.n.musum * nc_inv();
+        bu<false>(0, 0.0, 0.0, s.musum, s.open);
+        s.mu = s.musum * nc_inv();
         s.alpha = 1.0;
         s.kk = 0;
         s.diag = 0;
     }
     __device__ __forceinline__ bool cont(const State& s) const {
-        return s.kk < c.iter_max && s.alpha > c.alpha_min &&
-               (s.n.g > c.res_g_max || s.n.b > c.res_b_max || s.n.d > c.res_d_max ||
-                fabs(s.n.m - c.tau_min) > c.res_m_max);
+        return s.kk < c.iter_max && s.alpha > c.alpha_min && s.open;
     }
     // Barrier terms of the current point (what BU hands to the factorisation), recomputed for the
     // sequential redo of an iteration.
@@ -883,8 +901,8 @@ struct Wave : Algebra {
             }
             FwdOut fa;
             fw<false>(0, 0.0, fa);
-            const double a_aff = fa.a_prim < fa.a_dual ? fa.a_prim : fa.a_dual;
-            const double mu_aff0 = (s.n.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
+            const double a_aff = fa.alpha;
+            const double mu_aff0 = (s.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
             const double tmp = mu_aff0 / s.mu;
             const double sigma = tmp * tmp * tmp;
             sigma_mu = sigma * s.mu;
@@ -895,22 +913,22 @@ struct Wave : Algebra {
             for (;;) {
                 bw(mode, sigma_mu);
                 fw<true>(mode, sigma_mu, fc);
-                alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
+                alpha = fc.alpha;
                 if (mode == 2) break;
-                const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
+                const double mu_aff1 = (s.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
                 if (!(mu_aff1 > 2.0 * mu_aff0)) break;
                 mode = 2;
             }
-            if (!SCAN || attempt == 1 || fc.lin_g < c.scan_tol_lin) break;
+            if (!SCAN || attempt == 1 || !fc.lin_scan) break;
         }
         seq_now = false;
-        if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF;
-        if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;
+        if (fc.lin_itref) s.diag |= MPC_DIAG_ITREF;
+        if (fc.lin_lq) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
         double a_upd = alpha;
         if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
-        bu<false>(mode, sigma_mu, a_upd, s.n);
-        s.mu = s.n.musum * nci;
+        bu<false>(mode, sigma_mu, a_upd, s.musum, s.open);
+        s.mu = s.musum * nci;
         ++s.kk;
     }
 };
