@@ -479,8 +479,17 @@ struct Wave : Algebra {
     // Measured against the sequential recursion on the IPM's own matrices (barrier terms up to
     // 1e11): relative deviation of P <= 1e-14.
 
-    // affine suffix scan: on entry lane k (< N) holds p_k = T p_{k+1} + s, lane N holds (0, p_N);
-    // on exit s = p_k.
+    // The two affine scans need no "has a partner" guard when a wavefront holds one instance:
+    // an element that already reaches the end of its recursion has an exactly zero matrix
+    // (lane N / lane 0 start with 0, and 0 * finite = 0), so combining it with whatever the
+    // shuffle returns for a missing partner (its own value, 0, or a lane beyond N, which holds
+    // (0, 0)) leaves the vector unchanged bit for bit.  Without the branch the compiler needs no
+    // merge copies (42 v_mov for 39 FP64 instructions at distance 1).  With several instances per
+    // wavefront the guard stays: a neighbour's Inf/NaN must not leak through 0 * NaN.
+    static constexpr bool GUARD = X::PER_BLOCK > 1;
+
+    // affine suffix scan: on entry lane k (< N) holds p_k = T p_{k+1} + s, lane N holds (0, p_N),
+    // lanes beyond N hold (0, 0); on exit s = p_k.
     __device__ __forceinline__ void affine_suffix_scan(M3& T, double s[3]) const {
 #pragma unroll
         for (int d = 1; d < GW; d *= 2) {
@@ -488,7 +497,7 @@ struct Wave : Algebra {
             double s2[3] = {s[0], s[1], s[2]};
             if (2 * d < GW) x.down(T2.m, d);
             x.down(s2, d);
-            if (k + d <= N) {
+            if (!GUARD || k + d <= N) {
                 double r[3];
                 m3_mulv(T, s2, r);
 #pragma unroll
@@ -497,7 +506,8 @@ struct Wave : Algebra {
             }
         }
     }
-    // affine prefix scan: lane k (< N) holds dx_{k+1} = M dx_k + v with dx_0 = 0; on exit v = dx_{k+1}.
+    // affine prefix scan: lane k (< N) holds dx_{k+1} = M dx_k + v with dx_0 = 0, i.e. lane 0 holds
+    // (0, v_0); lanes from N on hold (0, 0); on exit v = dx_{k+1}.
     __device__ __forceinline__ void affine_prefix_scan(M3& M, double v[3]) const {
 #pragma unroll
         for (int d = 1; d < GW; d *= 2) {
@@ -505,7 +515,7 @@ struct Wave : Algebra {
             double v1[3] = {v[0], v[1], v[2]};
             if (2 * d < GW) x.up(M1.m, d);
             x.up(v1, d);
-            if (k >= d && mid) {
+            if (!GUARD || (k >= d && mid)) {
                 double r[3];
                 m3_mulv(M, v1, r);
 #pragma unroll
@@ -671,7 +681,7 @@ struct Wave : Algebra {
         } else {
 #pragma unroll
             for (int i = 0; i < 9; ++i) T.m[i] = 0.0;
-            s[0] = rg[2]; s[1] = rg[3]; s[2] = rg[4];   // lane N: p_N
+            s[0] = isN ? rg[2] : 0.0; s[1] = isN ? rg[3] : 0.0; s[2] = isN ? rg[4] : 0.0;   // lane N: p_N
         }
         affine_suffix_scan(T, s);
         double sn[3] = {s[0], s[1], s[2]};
@@ -694,6 +704,10 @@ struct Wave : Algebra {
         v[1] = rb[1] + (ab.B10 * kff[0] + ab.B11 * kff[1]);
         v[2] = rb[2] + (ab.B20 * kff[0] + ab.B21 * kff[1]);
         if (!mid) { v[0] = v[1] = v[2] = 0.0; }
+        if (!mid || is0) {   // dx_0 = 0: the stage-0 transition never acts
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
+        }
         affine_prefix_scan(M, v);
         nx0 = v[0]; nx1 = v[1]; nx2 = v[2];
         double dxv[3] = {nx0, nx1, nx2};
