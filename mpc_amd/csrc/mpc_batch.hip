@@ -122,7 +122,9 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     double* sN = col + ((size_t)(N * MPC_RPS) << 6);
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     X xpol = make_policy<X>(l);
-    Wave<X, SCAN> w(c, k, xpol);
+    // product cache of the scans (rti_wave.hpp build_products): [level][pair][lane] double2
+    __shared__ mc_d2 mc_lds[(X::MCACHE && SCAN) ? X::MC_LEVELS * MPC_MC_PAIRS * 64 : 1];
+    Wave<X, SCAN> w(c, k, xpol, mc_lds + (l & 63));
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll

@@ -89,6 +89,15 @@ __device__ __forceinline__ M3 m3_map(const M3& a, F f) {
     for (int i = 0; i < 9; ++i) r.m[i] = f(a.m[i]);
     return r;
 }
+// transposed product: r = a^T v
+__device__ __forceinline__ void m3_tmulv(const M3& a, const double v[3], double r[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = a.m[i] * v[0] + a.m[3 + i] * v[1] + a.m[6 + i] * v[2];
+}
+// LDS cache of the closed-loop products: [level][5 pairs][64 lanes] of double2 (ds_*_b128,
+// lane-contiguous); every lane only ever reads what it wrote itself, so no barrier is involved.
+typedef double mc_d2 __attribute__((ext_vector_type(2)));
+#define MPC_MC_PAIRS 5
 struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
 struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
 
@@ -99,6 +108,10 @@ struct XWave {
     static constexpr int LANES = GW;       // lanes per OCP
     static constexpr int THREADS = 64;     // workgroup size
     static constexpr int PER_BLOCK = 64 / GW;
+    // closed-loop products of all scan distances kept in LDS (Wave::build_products): one matrix
+    // per distance 1, 2, .., GW/2
+    static constexpr bool MCACHE = true;
+    static constexpr int MC_LEVELS = GW == 64 ? 6 : GW == 32 ? 5 : 4;
     template <int n> __device__ __forceinline__ void next(double (&v)[n]) const {
 #pragma unroll
         for (int i = 0; i < n; ++i) v[i] = lane_next(v[i]);
@@ -129,7 +142,7 @@ struct XWave {
         const unsigned long long b = __ballot(p);
         if (GW == 64) return b != 0ull;
         const int g = (int)(threadIdx.x & 63) / GW;
-        return ((b >> (g * GW)) & ((1ull << GW) - 1ull)) != 0ull;
+        return ((b >> (g * GW)) & (~0ull >> (64 - GW))) != 0ull;
     }
 };
 
@@ -143,6 +156,8 @@ struct XBlock {
     static constexpr int LANES = MPC_XB_LANES;
     static constexpr int THREADS = MPC_XB_LANES;
     static constexpr int PER_BLOCK = 1;
+    static constexpr bool MCACHE = false;   // (7 levels x 128 lanes would halve the blocks per CU)
+    static constexpr int MC_LEVELS = 0;
     double* lds;        // [2][MPC_XB_MAXN][128]
     int t;              // threadIdx.x
     mutable int slot;
@@ -202,6 +217,7 @@ struct Wave : Algebra {
     double ti[8];                // 1 / t of the current slacks (same bits as recomputing it in every pass)
     int wdiag = 0;               // MPC_DIAG_* bits raised inside the sweeps
     bool seq_now = false;        // SCAN build: use the sequential recursions (fallback of one iteration)
+    mc_d2* mc = nullptr;         // this lane's column of the product cache (X::MCACHE)
 
     struct State {
         int kk, diag;
@@ -210,8 +226,28 @@ struct Wave : Algebra {
         bool open;      // some residual norm is above its tolerance (the norm part of HPIPM's loop condition)
     };
 
-    __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_) : Algebra(c_), x(x_), k(stage), N(c_.N) {
+    __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_, mc_d2* mc_ = nullptr)
+        : Algebra(c_), x(x_), k(stage), N(c_.N), mc(mc_) {
         act = k <= N; mid = k < N; isN = k == N; is0 = k == 0;
+    }
+    __device__ __forceinline__ void mc_store(int level, const M3& M) const {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mc_d2 v; v.x = M.m[2 * q]; v.y = M.m[2 * q + 1];
+            mc[(level * MPC_MC_PAIRS + q) * 64] = v;
+        }
+        mc_d2 v; v.x = M.m[8]; v.y = 0.0;
+        mc[(level * MPC_MC_PAIRS + 4) * 64] = v;
+    }
+    __device__ __forceinline__ M3 mc_load(int level) const {
+        M3 M;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const mc_d2 v = mc[(level * MPC_MC_PAIRS + q) * 64];
+            M.m[2 * q] = v.x; M.m[2 * q + 1] = v.y;
+        }
+        M.m[8] = mc[(level * MPC_MC_PAIRS + 4) * 64].x;
+        return M;
     }
     __device__ __forceinline__ bool has_bound(int j) const { return mid && (j < 2 || !is0); }
     // Algebra::con_make with the cached reciprocals
@@ -533,6 +569,64 @@ struct Wave : Algebra {
         return F;
     }
 
+    // ---- X::MCACHE: the products of the closed-loop transitions are shared by all four vector
+    //      recursions of an IPM iteration (predictor and corrector, backward and forward), so
+    //      they are formed once per factorisation and parked in LDS:
+    //          M^(d)_k = Phi_k Phi_{k-1} .. Phi_{k-d+1},   d = 1, 2, .., GW/2,
+    //      with Phi_0 := 0 (dx_0 = 0) and Phi_k := 0 from stage N on.  The forward scan pulls
+    //      dx from lane k-d and applies its own M^(d)_k; the backward scan runs on
+    //      r_k = p_{k+1}: lane m forms (M^(d)_m)^T r_m, lane k pulls that from lane k+d (the
+    //      product over stages k+1..k+d is exactly the one lane k+d holds).  Each scan level
+    //      then moves 3 doubles and costs 9 FMA instead of 12 doubles and 36 FMA.
+    __device__ __forceinline__ void build_products() const {
+        M3 M = closed_loop();
+        if (!mid || is0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
+        }
+        mc_store(0, M);
+        int lvl = 1;
+#pragma unroll
+        for (int d = 1; 2 * d < GW; d *= 2, ++lvl) {
+            M3 M1 = M;
+            x.up(M1.m, d);
+            // (unguarded for one instance per wavefront: a product that reaches stage 0 is exactly 0)
+            if (!GUARD || k >= d) M = m3_mul(M, M1);
+            mc_store(lvl, M);
+        }
+    }
+    // backward: on entry s = s_k of p_k = Phi_k^T p_{k+1} + s_k (lane N: p_N, beyond: 0); on exit
+    // r = p_{k+1} in the lanes k < N
+    __device__ __forceinline__ void suffix_cached(const double s[3], double (&r)[3]) const {
+        r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
+        x.next(r);
+        if (!mid) { r[0] = r[1] = r[2] = 0.0; }
+        int lvl = 0;
+#pragma unroll
+        for (int d = 1; d < GW; d *= 2, ++lvl) {
+            const M3 Md = mc_load(lvl);
+            double cc[3];
+            m3_tmulv(Md, r, cc);
+            x.down(cc, d);
+            if (k + d < N) { r[0] += cc[0]; r[1] += cc[1]; r[2] += cc[2]; }
+        }
+    }
+    // forward: on entry v = v_k of dx_{k+1} = Phi_k dx_k + v_k (0 from lane N on); on exit v = dx_{k+1}
+    __device__ __forceinline__ void prefix_cached(double v[3]) const {
+        int lvl = 0;
+#pragma unroll
+        for (int d = 1; d < GW; d *= 2, ++lvl) {
+            double v1[3] = {v[0], v[1], v[2]};
+            x.up(v1, d);
+            const M3 Md = mc_load(lvl);
+            if (!GUARD || (k >= d && mid)) {
+                double rr[3];
+                m3_mulv(Md, v1, rr);
+                v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2];
+            }
+        }
+    }
+
     __device__ __forceinline__ bool factor_scan(const double Gam[4], const double gam[4]) {
         // --- elements ---
         M3 A;
@@ -578,7 +672,9 @@ struct Wave : Algebra {
                 for (int i = 0; i < 6; ++i) J2[i] = J[i];
                 x.down(J2, d);
             }
-            if (k + d <= N) {
+            // (unguarded as in the affine scans: an element that reaches the terminal stage has
+            //  A = 0 and C = 0 exactly, so W = I and J12 = J1 whatever the missing partner returns)
+            if (!GUARD || k + d <= N) {
                 const bool more = 2 * d < GW;   // A and C are only needed by later steps
                 // Xm = I + C1 J2
                 M3 Cm, Jm;
@@ -657,6 +753,7 @@ struct Wave : Algebra {
             if (bb[0] != 0.0) return false;
         }
 #endif
+        if (X::MCACHE) build_products();
         // --- affine right-hand side ---
         const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
         const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
@@ -667,26 +764,46 @@ struct Wave : Algebra {
 
     // p_k = (hxp + K^T hup) + Phi^T (q + p_{k+1}),  kff = -(Huu)^-1 (hup + B^T (q + p_{k+1}))
     __device__ __forceinline__ void rhs_scan(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
-        const M3 F = closed_loop();
-        M3 T;   // Phi^T
-        T.m[0] = F.m[0]; T.m[1] = F.m[3]; T.m[2] = F.m[6]; T.m[3] = F.m[1]; T.m[4] = F.m[4]; T.m[5] = F.m[7]; T.m[6] = F.m[2]; T.m[7] = F.m[5]; T.m[8] = F.m[8];
-        double s[3];
-        if (mid) {
-            const double qv[3] = {q0, q1, q2};
+        double p0, p1, p2;
+        if (X::MCACHE) {
+            // s_k with Phi_k^T q_k written out (the cached Phi_0 is zeroed; s_0 is not needed, p_0 is never formed)
+            const M3 F = closed_loop();
+            double s[3];
+            if (mid) {
+                const double qv[3] = {q0, q1, q2};
+                double r[3];
+                m3_tmulv(F, qv, r);
+                s[0] = (hxp0 + (K00 * hup0 + K10 * hup1)) + r[0];
+                s[1] = (hxp1 + (K01 * hup0 + K11 * hup1)) + r[1];
+                s[2] = (rg[4] + (K02 * hup0 + K12 * hup1)) + r[2];
+            } else {
+                s[0] = isN ? rg[2] : 0.0; s[1] = isN ? rg[3] : 0.0; s[2] = isN ? rg[4] : 0.0;
+            }
             double r[3];
-            m3_mulv(T, qv, r);
-            s[0] = (hxp0 + (K00 * hup0 + K10 * hup1)) + r[0];
-            s[1] = (hxp1 + (K01 * hup0 + K11 * hup1)) + r[1];
-            s[2] = (rg[4] + (K02 * hup0 + K12 * hup1)) + r[2];
+            suffix_cached(s, r);
+            p0 = r[0]; p1 = r[1]; p2 = r[2];
         } else {
+            const M3 F = closed_loop();
+            M3 T;   // Phi^T
+            T.m[0] = F.m[0]; T.m[1] = F.m[3]; T.m[2] = F.m[6]; T.m[3] = F.m[1]; T.m[4] = F.m[4]; T.m[5] = F.m[7]; T.m[6] = F.m[2]; T.m[7] = F.m[5]; T.m[8] = F.m[8];
+            double s[3];
+            if (mid) {
+                const double qv[3] = {q0, q1, q2};
+                double r[3];
+                m3_mulv(T, qv, r);
+                s[0] = (hxp0 + (K00 * hup0 + K10 * hup1)) + r[0];
+                s[1] = (hxp1 + (K01 * hup0 + K11 * hup1)) + r[1];
+                s[2] = (rg[4] + (K02 * hup0 + K12 * hup1)) + r[2];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) T.m[i] = 0.0;
-            s[0] = isN ? rg[2] : 0.0; s[1] = isN ? rg[3] : 0.0; s[2] = isN ? rg[4] : 0.0;   // lane N: p_N
+                for (int i = 0; i < 9; ++i) T.m[i] = 0.0;
+                s[0] = isN ? rg[2] : 0.0; s[1] = isN ? rg[3] : 0.0; s[2] = isN ? rg[4] : 0.0;   // lane N: p_N
+            }
+            affine_suffix_scan(T, s);
+            double sn[3] = {s[0], s[1], s[2]};
+            x.next(sn);
+            p0 = sn[0]; p1 = sn[1]; p2 = sn[2];
         }
-        affine_suffix_scan(T, s);
-        double sn[3] = {s[0], s[1], s[2]};
-        x.next(sn);
-        const double p0 = sn[0], p1 = sn[1], p2 = sn[2];
         if (mid) {
             pv[0] = p0; pv[1] = p1; pv[2] = p2;
             const double w0 = q0 + p0, w1 = q1 + p1, w2 = q2 + p2;
@@ -698,17 +815,21 @@ struct Wave : Algebra {
 
     // dx_{k+1} = Phi dx_k + (rb + B kff), dx_0 = 0;  du = kff + K dx
     __device__ __forceinline__ void fwd_scan(double& nx0, double& nx1, double& nx2, double dl[5]) {
-        M3 M = closed_loop();
         double v[3];
         v[0] = rb[0] + (ab.B00 * kff[0] + ab.B01 * kff[1]);
         v[1] = rb[1] + (ab.B10 * kff[0] + ab.B11 * kff[1]);
         v[2] = rb[2] + (ab.B20 * kff[0] + ab.B21 * kff[1]);
         if (!mid) { v[0] = v[1] = v[2] = 0.0; }
-        if (!mid || is0) {   // dx_0 = 0: the stage-0 transition never acts
+        if (X::MCACHE) {
+            prefix_cached(v);
+        } else {
+            M3 M = closed_loop();
+            if (!mid || is0) {   // dx_0 = 0: the stage-0 transition never acts
 #pragma unroll
-            for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
+                for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
+            }
+            affine_prefix_scan(M, v);
         }
-        affine_prefix_scan(M, v);
         nx0 = v[0]; nx1 = v[1]; nx2 = v[2];
         double dxv[3] = {nx0, nx1, nx2};
         x.prev(dxv);
