@@ -111,6 +111,14 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
  * mask [capacity] (host) selects capsules, NULL = all. */
 int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask);
 
+/* Shifted warm start.  No counterpart in the reference, whose capsules keep
+ * the previous iterate unshifted between ticks (src/optimizer.cpp:283-296); it is what an acados
+ * user does between RTI calls with ocp_nlp_out_get(stage + 1) / ocp_nlp_out_set(stage) loops:
+ * x_k <- x_{k+1}, u_k <- u_{k+1}, pi_k <- pi_{k+1}, lam_k <- lam_{k+1} for k = 0..N-2,
+ * x_{N-1} <- x_N; x_N, u_{N-1}, pi_{N-1}, lam_{N-1} are kept (the last interval is repeated).
+ * mask [capacity] (host) selects capsules, NULL = all. */
+int mpc_batch_shift(mpc_batch_t* h, const unsigned char* mask);
+
 /* Replaces ocp_nlp_out_get(.., stage, "x"|"u"|"pi", ..) for whole trajectories
  * (src/c_generated_code/main_mobile_robot.c:117-120).  Host pointers, any may be
  * NULL: xtraj [B][N+1][3], utraj [B][N][2], pi [B][N][3]. */
@@ -142,6 +150,10 @@ int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, in
  * density = 1/T/v_ref, window limit = floor(3.95 / (min(v_ref, 0.35 if v_ref > 0.3) * T)).
  * Does not touch the capsules' iterates (use mpc_batch_reset for that). */
 int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, double v_ref);
+
+/* on != 0: mpc_batch_track_run shifts every capsule's iterate (mpc_batch_shift) at the end of
+ * each tick.  Off by default = the reference's behaviour. */
+int mpc_batch_track_set_shift(mpc_batch_t* h, int on);
 
 /* Runs n_ticks control ticks for the first B vehicles and returns, after the last tick (any
  * pointer may be NULL): x [B][3] state, u [B][2] command in force (the previous one where the

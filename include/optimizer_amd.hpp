@@ -150,6 +150,7 @@ class Optimizer {
         double u0[2];
         int st = 0;
         if (mpc_batch_solve(mpc_, 1, i_current_state.data(), yref.data(), yref_e, u0, nullptr, nullptr, &st, nullptr)) st = 4;
+        if (shift_warm_start) mpc_batch_shift(mpc_, nullptr);
         status = st;
         if (status != 0) {
             std::cout << "ERROR!!! acados acados_ocp_solver returned status " << status << ". Exiting." << std::endl;
@@ -300,6 +301,7 @@ class Optimizer {
     int target_waypoint_index = 0, last_waypoint_index = 0, closest_waypoint_index = 0, num_waypoints = 0;
     Vector3d x_current, x_real, frame1, frame2, x_current_transformed;
     double u_current[2] = {0.0, 0.0};
+    bool shift_warm_start = false;   // extension (mpc_batch_shift); false = the reference's behaviour
     MatrixXd state_refs, input_refs;
     static constexpr double rdb_circumference = 3.95;
 

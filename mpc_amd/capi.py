@@ -26,6 +26,7 @@ EXPORTS = (
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
     "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model", "mpc_batch_get_diag",
+    "mpc_batch_shift", "mpc_batch_track_set_shift",
 )
 
 
@@ -83,6 +84,8 @@ def lib():
     L.mpc_batch_track_init.argtypes = [_vp, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]
     L.mpc_batch_track_run.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip]
     L.mpc_batch_set_model.argtypes = [_vp, ctypes.c_int]
+    L.mpc_batch_shift.argtypes = [_vp, ctypes.POINTER(ctypes.c_ubyte)]
+    L.mpc_batch_track_set_shift.argtypes = [_vp, ctypes.c_int]
     L.mpc_batch_get_diag.argtypes = [_vp, ctypes.c_int, _ip]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
@@ -220,6 +223,20 @@ class BatchSolver:
                 raise ValueError("mask must have one entry per capsule")
             rc = lib().mpc_batch_reset(self._h, m.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
         self._check(rc, "mpc_batch_reset")
+
+    def shift(self, mask=None):
+        """Shifted warm start: stage k of every (selected) capsule's iterate takes stage k+1's values."""
+        if mask is None:
+            rc = lib().mpc_batch_shift(self._h, None)
+        else:
+            m = np.ascontiguousarray(mask, np.uint8)
+            if m.shape != (self.capacity,):
+                raise ValueError("mask must have one entry per capsule")
+            rc = lib().mpc_batch_shift(self._h, m.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        self._check(rc, "mpc_batch_shift")
+
+    def track_set_shift(self, on):
+        self._check(lib().mpc_batch_track_set_shift(self._h, 1 if on else 0), "mpc_batch_track_set_shift")
 
     def sim_step(self, x, u):
         x = np.ascontiguousarray(x, np.float64).copy()

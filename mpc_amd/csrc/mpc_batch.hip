@@ -433,6 +433,33 @@ __global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
     }
 }
 
+// Shifted warm start on the capsule lines cap[instance][stage][MPC_CAP]: one workgroup per
+// instance; every thread reads its elements of line k+1 before anyone writes line k.
+#define MPC_SHIFT_THREADS 256
+#define MPC_SHIFT_PER_THREAD (((MPC_MAX_N + 1) * MPC_CAP + MPC_SHIFT_THREADS - 1) / MPC_SHIFT_THREADS)
+__global__ __launch_bounds__(MPC_SHIFT_THREADS) void k_shift(Mem m, int N, const unsigned char* mask, int n) {
+    const size_t i = blockIdx.x;
+    if (i >= (size_t)n) return;
+    if (mask && !mask[i]) return;   // uniform per workgroup
+    double* line = m.cap + i * (size_t)(N + 1) * MPC_CAP;
+    const int tot = N * MPC_CAP;    // destination elements: lines 0..N-1
+    double v[MPC_SHIFT_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < MPC_SHIFT_PER_THREAD; ++q) {
+        const int e = q * MPC_SHIFT_THREADS + threadIdx.x;
+        // line N only carries x_N: the controls and multipliers of the last interval stay
+        const bool take = e < tot && (e < (N - 1) * MPC_CAP || (e % MPC_CAP) < C_U);
+        v[q] = take ? line[e + MPC_CAP] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MPC_SHIFT_PER_THREAD; ++q) {
+        const int e = q * MPC_SHIFT_THREADS + threadIdx.x;
+        const bool take = e < tot && (e < (N - 1) * MPC_CAP || (e % MPC_CAP) < C_U);
+        if (take) line[e] = v[q];
+    }
+}
+
 // H16: plant step (mobile_robot_acados_sim_solve: ERK4, one step of Ts).
 __device__ __forceinline__ void plant_step(const Consts& c, double& x0, double& x1, double& psi, double v, double dl) {
     const double h = c.Ts;
@@ -583,6 +610,7 @@ struct mpc_batch {
     std::vector<Shard> shards;
     double last_ms = 0.0;
     int model = MPC_MODEL_AUTO;
+    int track_shift = 0;   // mpc_batch_track_set_shift
     double t_density = 0.0;   // tracker parameters (mpc_batch_track_init)
     int t_limit = 0;
     std::string err;
@@ -1018,6 +1046,34 @@ int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
     return 0;
 }
 
+int mpc_batch_shift(mpc_batch_t* h, const unsigned char* mask) {
+    if (!h) return -1;
+    const int N = h->spec.N;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        if (mask) HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
+        hipLaunchKernelGGL(k_shift, dim3(s.cap), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem, N,
+                           mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
+        HIPCHK(h, hipGetLastError());
+    }
+    for (Shard& s : h->shards) {
+        if (s.cap <= 0) continue;
+        HIPCHK(h, hipSetDevice(s.device));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+int mpc_batch_track_set_shift(mpc_batch_t* h, int on) {
+    if (!h) return -1;
+    h->track_shift = on ? 1 : 0;
+    return 0;
+}
+
 int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* pi) {
     if (!h || B < 1 || B > h->capacity) return -1;
     const int N = h->spec.N;
@@ -1159,6 +1215,9 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
             int rc = enqueue_core(h, s, n, s.stream);
             if (rc != 0) { (void)hipSetDevice(prev); return rc; }
             hipLaunchKernelGGL(k_track_advance, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
+            if (h->track_shift)
+                hipLaunchKernelGGL(k_shift, dim3(n), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem, h->spec.N,
+                                   (const unsigned char*)nullptr, n);
         }
         HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         HIPCHK(h, hipGetLastError());

@@ -67,7 +67,10 @@ class Optimizer:
 
     def __init__(self, T, N, v_ref, x_init=0.83, y_init=0.33, yaw_init=1.65756, *, state_refs=None,
                  input_refs=None, state_attributes=None, normals=None, paths_dir=None, path_name="_path1",
-                 solver_factory=None):
+                 solver_factory=None, shift_warm_start=False):
+        # shift_warm_start: shift the solver's iterate by one stage after every tick (SURVEY §8f-2;
+        # off = the reference, which keeps the previous iterate as it is)
+        self.shift_warm_start = bool(shift_warm_start)
         self.T, self.v_ref = float(T), float(v_ref)
         self.density = 1.0 / self.T / self.v_ref
         self.region_of_acceptance = 0.03076923 * 3 * (0.125 * 1.3) / self.density
@@ -208,6 +211,8 @@ class Optimizer:
         self.x_state[:3] = yref[self.N - 1, :3]
         x0 = np.asarray(i_current_state, np.float64).reshape(1, 3)
         out = self._solver.solve(x0, yref[None], yref_e[None])
+        if self.shift_warm_start:
+            self._solver.shift()
         self.status = int(out["status"][0])
         if self.status != 0:
             return 1

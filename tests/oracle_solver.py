@@ -24,6 +24,11 @@ class OracleSolver:
         self.xtraj[:B], self.utraj[:B] = r["xtraj"], r["utraj"]
         return r
 
+    def shift(self, mask=None):
+        sel = slice(None) if mask is None else np.asarray(mask, bool)
+        self.xtraj[sel, :-1] = self.xtraj[sel, 1:]
+        self.utraj[sel, :-1] = self.utraj[sel, 1:]
+
     def sim_step(self, x, u):
         return oracle_lib.sim_step(self.spec, x, u)
 

@@ -585,3 +585,69 @@ def test_workgroup_variant_of_the_wave_model(oracle, N):
     assert np.array_equal(ro["status"], rg["status"]) and np.array_equal(ro["sqp_iter"], sit)
     assert np.abs(ro["utraj"] - ug).max() < TOL_PATH
     s2.close()
+
+
+def test_shift_moves_every_stage_one_down(oracle):
+    """mpc_batch_shift: x_k <- x_{k+1}, u_k <- u_{k+1}, pi_k <- pi_{k+1}, the last
+    interval repeated; masked capsules untouched; the next solve starts from the shifted iterate
+    exactly as the oracle does from the same arrays."""
+    B = 130
+    sp, wl = workload.make("mobile_robot", B)
+    solver = capi.BatchSolver(sp, B)
+    x0, yref, yref_e = wl.tick(0)
+    solver.solve(x0, yref, yref_e)
+    xt, ut, pi = solver.get(B)
+    mask = np.ones(B, np.uint8); mask[::3] = 0
+    solver.shift(mask)
+    xs, us, ps = solver.get(B)
+    keep = mask == 0
+    assert np.array_equal(xs[keep], xt[keep]) and np.array_equal(us[keep], ut[keep]) and np.array_equal(ps[keep], pi[keep])
+    mv = ~keep
+    assert np.array_equal(xs[mv, :-1], xt[mv, 1:]) and np.array_equal(xs[mv, -1], xt[mv, -1])
+    assert np.array_equal(us[mv, :-1], ut[mv, 1:]) and np.array_equal(us[mv, -1], ut[mv, -1])
+    assert np.array_equal(ps[mv, :-1], pi[mv, 1:]) and np.array_equal(ps[mv, -1], pi[mv, -1])
+    solver.shift()          # everything once more, then solve the next window from there
+    xs2, us2, _ = solver.get(B)
+    assert np.array_equal(xs2[:, :-1], xs[:, 1:]) and np.array_equal(us2[:, :-1], us[:, 1:])
+    x0, yref, yref_e = wl.tick(1)
+    ro = oracle.rti_batch(sp, x0, yref, yref_e, xs2, us2)
+    rg = solver.solve(x0, yref, yref_e)
+    assert np.array_equal(ro["status"], rg["status"]) and np.array_equal(ro["qp_iter"], rg["qp_iter"])
+    assert np.abs(ro["u0"] - rg["u0"]).max() < TOL_PATH
+    solver.close()
+
+
+def test_device_closed_loop_with_shifted_warm_start(oracle):
+    """mpc_batch_track_set_shift: the device loop with the shift after every tick against host-side
+    `Optimizer(shift_warm_start=True)` mirrors on the oracle."""
+    import os
+    from mpc_amd.optimizer import Optimizer, load_txt
+    from tests.oracle_solver import OracleSolver
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))
+    u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))
+    B, T, v_ref = 24, 0.1, 0.5
+    rng = np.random.Generator(np.random.PCG64(12))
+    start = s[rng.integers(0, 60, B)] + rng.normal(0, 1, (B, 3)) * np.array([0.05, 0.05, 0.1])
+    opts = [Optimizer(T, 40, v_ref, *start[i], state_refs=s, input_refs=u, solver_factory=OracleSolver,
+                      shift_warm_start=True) for i in range(B)]
+    solver = capi.BatchSolver(opts[0].spec, B)
+    solver.track_set_path(s, u)
+    solver.track_init(start, T, v_ref)
+    solver.track_set_shift(True)
+    for k in range(25):
+        r = solver.track_run(1)
+        for i, o in enumerate(opts):
+            rc = o.update_and_solve(o.x_current)
+            o.integrate_next_states()
+            assert (rc == 0) == (r["status"][i] == 0)
+            assert o.target_waypoint_index == r["target"][i], (k, i)
+        uo = np.array([o.u_current for o in opts]); xo = np.array([o.x_current for o in opts])
+        assert np.abs(uo - r["u"]).max() < TOL_HARD and np.abs(xo - r["x"]).max() < TOL_HARD, k
+    # differs from the unshifted loop (the option does something)
+    solver2 = capi.BatchSolver(opts[0].spec, B)
+    solver2.track_set_path(s, u)
+    solver2.track_init(start, T, v_ref)
+    r2 = solver2.track_run(25)
+    assert np.abs(r2["x"] - r["x"]).max() > 1e-9
+    solver.close(); solver2.close()

@@ -189,3 +189,17 @@ def test_run_reaches_the_end_of_a_short_path():
     assert n < 400
     assert np.linalg.norm(s[-1] - o.x_current) < 0.1
     assert abs(o.t0 - n * o.T) < 1e-9
+
+
+def test_shift_warm_start_option_shifts_the_solver_iterate():
+    """shift_warm_start=True: after a tick the stand-in's stored iterate is the
+    solution moved one stage down; off (the reference) it is the solution itself."""
+    s, u = path150()
+    a = Optimizer(0.1, 40, 0.5, *s[0], state_refs=s, input_refs=u, solver_factory=OracleSolver)
+    b = Optimizer(0.1, 40, 0.5, *s[0], state_refs=s, input_refs=u, solver_factory=OracleSolver, shift_warm_start=True)
+    assert a.update_and_solve(a.x_current) == 0 and b.update_and_solve(b.x_current) == 0
+    assert np.array_equal(a.u_current, b.u_current)
+    xa, xb = a._solver.xtraj[0], b._solver.xtraj[0]
+    assert np.array_equal(xb[:-1], xa[1:]) and np.array_equal(xb[-1], xa[-1])
+    ua, ub = a._solver.utraj[0], b._solver.utraj[0]
+    assert np.array_equal(ub[:-1], ua[1:]) and np.array_equal(ub[-1], ua[-1])
