@@ -766,8 +766,9 @@ struct Wave : Algebra {
     __device__ __forceinline__ void rhs_scan(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
         double p0, p1, p2;
         if (X::MCACHE) {
-            // s_k with Phi_k^T q_k written out (the cached Phi_0 is zeroed; s_0 is not needed, p_0 is never formed)
-            const M3 F = closed_loop();
+            // s_k with Phi_k^T q_k written out; Phi_k from the cache (its Phi_0 is zeroed, but s_0 is
+            // not needed: p_0 is never formed)
+            const M3 F = mc_load(0);
             double s[3];
             if (mid) {
                 const double qv[3] = {q0, q1, q2};
