@@ -57,9 +57,28 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
     v = op(v, lane_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
     v = op(v, lane_dpp<0x141>(v));   // row_half_mirror
     v = op(v, lane_dpp<0x140>(v));   // row_mirror
-    // (reading one lane per row with v_readlane and combining in SGPRs was measured 3 % slower)
+    // (reading one lane per row with v_readlane and combining the four was measured 3 % slower)
+    if (GW == 64) {
+        // cross-row steps without LDS: row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3,
+        // then the total sits in lane 63 and is broadcast through a scalar register pair
+        // (measured 1.5 % faster than two ds_bpermute round trips)
+        {
+            const double nt = op.neutral(v);
+            int lo = __builtin_amdgcn_update_dpp(__double2loint(nt), __double2loint(v), 0x142, 0xa, 0xf, false);
+            int hi = __builtin_amdgcn_update_dpp(__double2hiint(nt), __double2hiint(v), 0x142, 0xa, 0xf, false);
+            v = op(v, __hiloint2double(hi, lo));
+        }
+        {
+            const double nt = op.neutral(v);
+            int lo = __builtin_amdgcn_update_dpp(__double2loint(nt), __double2loint(v), 0x143, 0xc, 0xf, false);
+            int hi = __builtin_amdgcn_update_dpp(__double2hiint(nt), __double2hiint(v), 0x143, 0xc, 0xf, false);
+            v = op(v, __hiloint2double(hi, lo));
+        }
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+        return __hiloint2double(hi, lo);
+    }
     if (GW >= 32) v = op(v, __shfl_xor(v, 16, 64));
-    if (GW >= 64) v = op(v, __shfl_xor(v, 32, 64));
     return v;
 }
 // lane i <- lane i+d / lane i-d for any d (ds_bpermute); what a lane without a source gets is
@@ -98,8 +117,14 @@ __device__ __forceinline__ void m3_tmulv(const M3& a, const double v[3], double 
 // lane-contiguous); every lane only ever reads what it wrote itself, so no barrier is involved.
 typedef double mc_d2 __attribute__((ext_vector_type(2)));
 #define MPC_MC_PAIRS 5
-struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
-struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax {
+    __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); }
+    __device__ __forceinline__ double neutral(double v) const { return v; }
+};
+struct OpSum {
+    __device__ __forceinline__ double operator()(double a, double b) const { return a + b; }
+    __device__ __forceinline__ double neutral(double) const { return 0.0; }
+};
 
 // ---- cross-lane policies ---------------------------------------------------------------
 // XWave<GW>: one OCP per GW lanes of a wavefront (GW = 64, 32, 16) — DPP / ds_bpermute.
@@ -578,36 +603,38 @@ struct Wave : Algebra {
     //      r_k = p_{k+1}: lane m forms (M^(d)_m)^T r_m, lane k pulls that from lane k+d (the
     //      product over stages k+1..k+d is exactly the one lane k+d holds).  Each scan level
     //      then moves 3 doubles and costs 9 FMA instead of 12 doubles and 36 FMA.
-    __device__ __forceinline__ void build_products() const {
-        M3 M = closed_loop();
-        if (!mid || is0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
-        }
-        mc_store(0, M);
-        int lvl = 1;
-#pragma unroll
-        for (int d = 1; 2 * d < GW; d *= 2, ++lvl) {
-            M3 M1 = M;
-            x.up(M1.m, d);
-            // (unguarded for one instance per wavefront: a product that reaches stage 0 is exactly 0)
-            if (!GUARD || k >= d) M = m3_mul(M, M1);
-            mc_store(lvl, M);
-        }
-    }
     // backward: on entry s = s_k of p_k = Phi_k^T p_{k+1} + s_k (lane N: p_N, beyond: 0); on exit
     // r = p_{k+1} in the lanes k < N
+    // BUILD: the first backward scan after a factorisation also forms and stores the products
+    // (the two shuffles of a level travel together: one LDS round trip instead of two).
+    template <bool BUILD>
     __device__ __forceinline__ void suffix_cached(const double s[3], double (&r)[3]) const {
         r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
         x.next(r);
         if (!mid) { r[0] = r[1] = r[2] = 0.0; }
+        M3 M;
+        if (BUILD) {
+            M = closed_loop();
+            if (!mid || is0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) M.m[i] = 0.0;
+            }
+            mc_store(0, M);
+        }
         int lvl = 0;
 #pragma unroll
         for (int d = 1; d < GW; d *= 2, ++lvl) {
-            const M3 Md = mc_load(lvl);
+            const M3 Md = BUILD ? M : mc_load(lvl);
             double cc[3];
             m3_tmulv(Md, r, cc);
             x.down(cc, d);
+            if (BUILD && 2 * d < GW) {
+                M3 M1 = M;
+                x.up(M1.m, d);
+                // (unguarded for one instance per wavefront: a product that reaches stage 0 is exactly 0)
+                if (!GUARD || k >= d) M = m3_mul(M, M1);
+                mc_store(lvl + 1, M);
+            }
             if (k + d < N) { r[0] += cc[0]; r[1] += cc[1]; r[2] += cc[2]; }
         }
     }
@@ -753,22 +780,23 @@ struct Wave : Algebra {
             if (bb[0] != 0.0) return false;
         }
 #endif
-        if (X::MCACHE) build_products();
         // --- affine right-hand side ---
         const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
         const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
         const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
-        rhs_scan(rg[0] + gam[0], rg[1] + gam[1], rg[2] + gam[2], rg[3] + gam[3], q0, q1, q2);
+        rhs_scan<true>(rg[0] + gam[0], rg[1] + gam[1], rg[2] + gam[2], rg[3] + gam[3], q0, q1, q2);
         return true;
     }
 
     // p_k = (hxp + K^T hup) + Phi^T (q + p_{k+1}),  kff = -(Huu)^-1 (hup + B^T (q + p_{k+1}))
+    // FIRST: the first right-hand side after a factorisation (forms the product cache on the way)
+    template <bool FIRST>
     __device__ __forceinline__ void rhs_scan(double hup0, double hup1, double hxp0, double hxp1, double q0, double q1, double q2) {
         double p0, p1, p2;
         if (X::MCACHE) {
             // s_k with Phi_k^T q_k written out; Phi_k from the cache (its Phi_0 is zeroed, but s_0 is
             // not needed: p_0 is never formed)
-            const M3 F = mc_load(0);
+            const M3 F = FIRST ? closed_loop() : mc_load(0);
             double s[3];
             if (mid) {
                 const double qv[3] = {q0, q1, q2};
@@ -781,7 +809,7 @@ struct Wave : Algebra {
                 s[0] = isN ? rg[2] : 0.0; s[1] = isN ? rg[3] : 0.0; s[2] = isN ? rg[4] : 0.0;
             }
             double r[3];
-            suffix_cached(s, r);
+            suffix_cached<FIRST>(s, r);
             p0 = r[0]; p1 = r[1]; p2 = r[2];
         } else {
             const M3 F = closed_loop();
@@ -858,7 +886,7 @@ struct Wave : Algebra {
         const double q2 = P.p20 * rb[0] + P.p21 * rb[1] + P.p22 * rb[2];
         const double hup0 = rg[0] + gam[0], hup1 = rg[1] + gam[1];
         const double hxp0 = rg[2] + gam[2], hxp1 = rg[3] + gam[3];
-        if (SCAN && !seq_now) rhs_scan(hup0, hup1, hxp0, hxp1, q0, q1, q2);
+        if (SCAN && !seq_now) rhs_scan<false>(hup0, hup1, hxp0, hxp1, q0, q1, q2);
         else rhs_seq(hup0, hup1, hxp0, hxp1, q0, q1, q2);
     }
 
