@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v5):
-# FETCH_SIZE 2.90e5 KiB x 2 (gfx950 correction of the guide) + WRITE_SIZE 3.75e5 KiB
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 0.98e9
+# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v7):
+# FETCH_SIZE 2.90e5 KiB x 2 (gfx950 correction of the guide) + WRITE_SIZE 3.65e5 KiB
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 0.97e9
 
 
 def algorithmic_bytes_per_solve(N):

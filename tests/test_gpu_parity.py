@@ -651,3 +651,30 @@ def test_device_closed_loop_with_shifted_warm_start(oracle):
     r2 = solver2.track_run(25)
     assert np.abs(r2["x"] - r["x"]).max() > 1e-9
     solver.close(); solver2.close()
+
+
+@pytest.mark.parametrize("N", [50, 25, 15])
+def test_non_finite_inputs_stay_inside_their_instance(N):
+    """Several OCPs can share a wavefront (N <= 31) and the scans shuffle across lanes without a
+    partner guard where one OCP owns the wavefront: an instance fed NaN / Inf must not change a
+    single bit of any other instance's result, and must itself come back failed."""
+    B = 203
+    sp, wl = workload.make("mobile_robot", B, N=N)
+    x0, yref, yref_e = wl.tick(0)
+    clean = capi.BatchSolver(sp, B)
+    rc = clean.solve(x0, yref, yref_e)
+    xc, uc, _ = clean.get(B, want_pi=False)
+    bad = np.zeros(B, bool); bad[[0, 5, 6, 64, 127, 130, 202]] = True
+    x0p, yrefp = x0.copy(), yref.copy()
+    x0p[[0, 5, 64]] = np.nan
+    x0p[6, 2] = np.inf
+    yrefp[[127, 130, 202], N // 2, 0] = np.nan
+    dirty = capi.BatchSolver(sp, B)
+    rd = dirty.solve(x0p, yrefp, yref_e)
+    xd, ud, _ = dirty.get(B, want_pi=False)
+    ok = ~bad
+    assert np.array_equal(rd["status"][ok], rc["status"][ok]) and np.array_equal(rd["qp_iter"][ok], rc["qp_iter"][ok])
+    assert np.array_equal(rd["u0"][ok], rc["u0"][ok])
+    assert np.array_equal(ud[ok], uc[ok]) and np.array_equal(xd[ok], xc[ok])
+    assert (rd["status"][bad] != 0).all()
+    clean.close(); dirty.close()
