@@ -10,10 +10,11 @@
 //   * everything that is local to a stage (ERK4 + sensitivities, cold start, residuals,
 //     complementarity algebra, step lengths, variable update) runs on all stages at once;
 //   * neighbour access (pi_{k-1}, x_{k+1}) is one DPP wave shift;
-//   * norms, mu and the step lengths are wavefront reductions (DPP butterfly inside a row,
-//     ds_bpermute across rows);
+//   * mu and the step lengths are wavefront reductions (DPP butterfly inside a row, DPP
+//     row_bcast across rows); the residual-norm tests are group ballots;
 //   * the Riccati recursion and the two substitutions are parallel scans over the stages
-//     (factor_scan / rhs_scan / fwd_scan below); the sequential forms (lane k computes under
+//     (factor_scan / rhs_scan / fwd_scan below), the closed-loop products they share are kept
+//     in LDS per factorisation (suffix_cached / prefix_cached); the sequential forms (lane k computes under
 //     `if (lane == k)`, P/p or dx move one lane over per step) remain as the in-kernel fallback
 //     of the acceptance test and as the WAVE_SEQ cross-check model.
 // The per-stage arithmetic is rti_core.hpp's Algebra (same formulas, same order as the
@@ -133,7 +134,7 @@ struct XWave {
     static constexpr int LANES = GW;       // lanes per OCP
     static constexpr int THREADS = 64;     // workgroup size
     static constexpr int PER_BLOCK = 64 / GW;
-    // closed-loop products of all scan distances kept in LDS (Wave::build_products): one matrix
+    // closed-loop products of all scan distances kept in LDS (Wave::suffix_cached<true>): one matrix
     // per distance 1, 2, .., GW/2
     static constexpr bool MCACHE = true;
     static constexpr int MC_LEVELS = GW == 64 ? 6 : GW == 32 ? 5 : 4;
