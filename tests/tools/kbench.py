@@ -2,7 +2,7 @@
 """Quick kernel timing for development: per-tick device time of mpc_batch_solve_device at a few
 batch sizes (cold tick 0, then warm ticks), plus a parity spot check against the oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from mpc_amd import capi, workload

@@ -3,7 +3,7 @@
 its own iterate; (2) 65536 vehicles x 300 closed-loop ticks on the device; (3) full SQP, 131072
 instances (BASELINE config 5, one GPU's share)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mpc_amd import capi, workload, variants
 from mpc_amd.optimizer import load_txt
@@ -24,7 +24,7 @@ for t in range(20):
 print(f"(1) 20 ticks x {B}: max|du| {worst:.2e}, min fraction equal qp_iter {same_min:.5f}, diag bits {diag_any}", flush=True)
 s.close()
 
-g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden")
 sr = load_txt(os.path.join(g, "state_refs_path150_head.txt")); ur = load_txt(os.path.join(g, "input_refs_path150_head.txt"))
 Bv = 65536
 rng = np.random.Generator(np.random.PCG64(2))

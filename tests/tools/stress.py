@@ -2,7 +2,7 @@
 """Stress of the scan numerics: state bounds tightened around the start positions so that the
 barrier terms of the x/y bounds (which enter J of the Riccati scan) become active."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mpc_amd import capi, workload
 from tests import oracle_lib

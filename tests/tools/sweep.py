@@ -2,7 +2,7 @@
 """Randomised parity sweep (development aid): several seeds x variants x warm ticks, GPU (default
 model) against the oracle; prints the worst deviation and any status / iteration-count mismatch."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mpc_amd import capi, workload
 from tests import oracle_lib
