@@ -616,6 +616,15 @@ struct mpc_batch {
     std::string err;
 };
 
+// Restores the caller's current device on every exit path of an entry point (HIPCHK returns early).
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() { }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 #define HIPCHK(h, call)                                                                  \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -861,8 +870,7 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
     const int N = spec->N;
     const int nd = (int)devs.size();
     const int per = (capacity + nd - 1) / nd;
-    int prev_dev = 0;
-    (void)hipGetDevice(&prev_dev);
+    DeviceGuard device_guard;
     h->shards.resize(nd);
     int rc = 0;
     for (int d = 0; d < nd && rc == 0; ++d) {
@@ -911,7 +919,6 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
         };
         rc = body();
     }
-    (void)hipSetDevice(prev_dev);
     if (rc != 0) {
         fprintf(stderr, "mpc_batch_create: %s\n", h->err.c_str());
         for (Shard& s : h->shards) free_shard(s);
@@ -924,10 +931,8 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
 
 void mpc_batch_free(mpc_batch_t* h) {
     if (!h) return;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) free_shard(s);
-    (void)hipSetDevice(prev);
     delete h;
 }
 
@@ -938,13 +943,11 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
     if (h->shards.size() != 1) { h->err = "mpc_batch_solve_device needs a single-device handle"; return -1; }
     Shard& s = h->shards[0];
     hipStream_t st = stream ? (hipStream_t)stream : s.stream;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     HIPCHK(h, hipSetDevice(s.device));
     HIPCHK(h, hipEventRecord(s.ev0, st));
     int rc = enqueue_solve(h, s, B, d_x0, d_yref, d_yref_e, d_u0, d_xtraj, d_utraj, d_status, d_qp_iter, st);
     if (rc == 0) HIPCHK(h, hipEventRecord(s.ev1, st));
-    (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -953,8 +956,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
     if (!h || B < 1 || B > h->capacity || !x0 || !yref || !yref_e) return -1;
     if ((xtraj == nullptr) != (utraj == nullptr)) { h->err = "xtraj and utraj must be given together"; return -1; }
     const int N = h->spec.N;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     if (h->shards.size() == 1 && B <= MPC_ZEROCOPY_MAX && !xtraj && pick_model(h) != MPC_MODEL_LANE) {
         // latency path (the reference's batch = 1 control loop): inputs are staged in pinned
         // host memory that k_wave reads directly, outputs are written straight into pinned
@@ -973,7 +975,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         WaveIO io = {zx0, zyr, zye, zu0, zst, zit};
         HIPCHK(h, hipEventRecord(s.ev0, s.stream));
         int rc = enqueue_core(h, s, B, s.stream, &io);
-        if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+        if (rc != 0) return rc;
         HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
         if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
@@ -981,7 +983,6 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         if (qp_iter) memcpy(qp_iter, zit, sizeof(int) * B);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) h->last_ms = ms;
-        (void)hipSetDevice(prev);
         return 0;
     }
     // enqueue on every shard, then wait for all: shards run concurrently
@@ -1000,7 +1001,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         HIPCHK(h, hipEventRecord(s.ev0, s.stream));
         int rc = enqueue_solve(h, s, n, s.s_x0, s.s_yref, s.s_yrefe, s.s_u0, xtraj ? s.s_xt : nullptr,
                                xtraj ? s.s_ut : nullptr, nullptr, nullptr, s.stream);
-        if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+        if (rc != 0) return rc;
         HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
         if (xtraj) {
@@ -1020,15 +1021,13 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess && ms > worst) worst = ms;
     }
     h->last_ms = worst;
-    (void)hipSetDevice(prev);
     return 0;
 }
 
 int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
     if (!h) return -1;
     const int N = h->spec.N;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         if (s.cap <= 0) continue;
         HIPCHK(h, hipSetDevice(s.device));
@@ -1042,15 +1041,13 @@ int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
 int mpc_batch_shift(mpc_batch_t* h, const unsigned char* mask) {
     if (!h) return -1;
     const int N = h->spec.N;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         if (s.cap <= 0) continue;
         HIPCHK(h, hipSetDevice(s.device));
@@ -1064,7 +1061,6 @@ int mpc_batch_shift(mpc_batch_t* h, const unsigned char* mask) {
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
@@ -1078,8 +1074,7 @@ int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* p
     if (!h || B < 1 || B > h->capacity) return -1;
     const int N = h->spec.N;
 
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
@@ -1104,14 +1099,12 @@ int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* p
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
 int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u) {
     if (!h || B < 1 || B > h->capacity || !x || !u) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
@@ -1128,7 +1121,6 @@ int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u) {
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
@@ -1153,8 +1145,7 @@ static Track make_track(const mpc_batch* h, const Shard& s) {
 
 int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, int Mi, const double* input_refs) {
     if (!h || M < 1 || Mi < 1 || !state_refs || !input_refs) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         if (s.cap <= 0) continue;
         HIPCHK(h, hipSetDevice(s.device));
@@ -1167,7 +1158,6 @@ int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, in
         HIPCHK(h, hipMemcpy(s.t_iref, input_refs, sizeof(double) * 2 * Mi, hipMemcpyHostToDevice));
         s.t_M = M; s.t_Mi = Mi;
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
@@ -1177,12 +1167,11 @@ int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, 
     h->t_density = 1.0 / T / v_ref;
     const double v_lim = v_ref > 0.3 ? 0.35 : v_ref;
     h->t_limit = (int)floor(3.95 / (v_lim * T));
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
-        if (!s.t_sref) { h->err = "mpc_batch_track_init: call mpc_batch_track_set_path first"; (void)hipSetDevice(prev); return -1; }
+        if (!s.t_sref) { h->err = "mpc_batch_track_init: call mpc_batch_track_set_path first"; return -1; }
         HIPCHK(h, hipSetDevice(s.device));
         if (!s.t_x) {
             HIPCHK(h, hipMalloc(&s.t_x, sizeof(double) * 3 * s.S));
@@ -1194,18 +1183,16 @@ int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, 
         HIPCHK(h, hipMemsetAsync(s.t_idx, 0, sizeof(int) * 4 * s.S, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
 int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u, int* target, int* status) {
     if (!h || B < 1 || B > h->capacity || n_ticks < 0) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
-        if (!s.t_x) { h->err = "mpc_batch_track_run: call mpc_batch_track_init first"; (void)hipSetDevice(prev); return -1; }
+        if (!s.t_x) { h->err = "mpc_batch_track_run: call mpc_batch_track_init first"; return -1; }
         HIPCHK(h, hipSetDevice(s.device));
         const Track tr = make_track(h, s);
         const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
@@ -1213,7 +1200,7 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
         for (int t = 0; t < n_ticks; ++t) {
             hipLaunchKernelGGL(k_track_select, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
             int rc = enqueue_core(h, s, n, s.stream);
-            if (rc != 0) { (void)hipSetDevice(prev); return rc; }
+            if (rc != 0) return rc;
             hipLaunchKernelGGL(k_track_advance, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
             if (h->track_shift)
                 hipLaunchKernelGGL(k_shift, dim3(n), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem, h->spec.N,
@@ -1242,14 +1229,12 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
         }
     }
     h->last_ms = worst;
-    (void)hipSetDevice(prev);
     return 0;
 }
 
 int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag) {
     if (!h || B < 1 || B > h->capacity || !diag) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
@@ -1257,7 +1242,6 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag) {
         HIPCHK(h, hipStreamSynchronize(s.stream));
         HIPCHK(h, hipMemcpy(diag + s.first, s.mem.DIAG, sizeof(int) * n, hipMemcpyDeviceToHost));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
@@ -1271,8 +1255,7 @@ int mpc_batch_set_model(mpc_batch_t* h, int model) {
 // (stat, eq, ineq, comp) of the last solve.  Host pointers, either may be NULL.
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {
     if (!h || B < 1 || B > h->capacity) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
@@ -1281,7 +1264,6 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {
         if (sqp_iter) HIPCHK(h, hipMemcpy(sqp_iter + s.first, s.mem.SQPITER, sizeof(int) * n, hipMemcpyDeviceToHost));
         if (res4) HIPCHK(h, hipMemcpy(res4 + 4 * (size_t)s.first, s.mem.NLPRES, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 // Development/diagnostic: live-instance counts at the start of phases 1..7 of the last solve
@@ -1289,12 +1271,10 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {
 int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8) {
     if (!h || !out8 || h->shards.empty()) return -1;
     Shard& s = h->shards[0];
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard device_guard;
     HIPCHK(h, hipSetDevice(s.device));
     HIPCHK(h, hipStreamSynchronize(s.stream));
     HIPCHK(h, hipMemcpy(out8, s.phase_ints, MPC_MAX_PHASES * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipSetDevice(prev);
     return 0;
 }
 // Device time of the first (dense, HBM-bound) k_phase launch of the last solve on the first
