@@ -620,7 +620,7 @@ struct mpc_batch {
 struct DeviceGuard {
     int prev = 0;
     DeviceGuard() { (void)hipGetDevice(&prev); }
-    ~DeviceGuard() { }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
