@@ -86,8 +86,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The collective backend only carries the barrier and the max-over-ranks time (no
+        # collective on the data path); if RCCL cannot start on this node the measurement falls
+        # back to gloo for those two calls and says so in the JSON line.
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: nccl/RCCL unavailable ({e}); using gloo for barrier/all_reduce", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                args.backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
@@ -153,7 +165,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.variant} N={N} Ts={sp.Ts} SQP-RTI (HPIPM BALANCE, qp_iter_max {sp.qp_iter_max}), "
                                    f"{B} arc-tracking instances per GPU, warm iterate, seed {workload.SEED}",
-                       "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (independent shards, no collective)"},
+                       "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (independent shards, no collective)",
+                       "barrier_backend": (("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None)},
             "mean_qp_iter": mean_it, "max_qp_iter": int(qp_iter_last.max()),
             "failed_instances": int((status_last != 0).sum()),
             "kernel_ms_per_step": mean_kernel_ms,
