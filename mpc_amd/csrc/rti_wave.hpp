@@ -953,7 +953,13 @@ struct Wave : Algebra {
         double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (SCAN && !seq_now) fwd_scan(nx0, nx1, nx2, dl);
         else fwd_seq(nx0, nx1, nx2, dl);
-        double pn = 1.0, pd = -1.0, dn = 1.0, dd = -1.0;   // step-length candidates as ratios n / d = -1
+        // Step length in inverse form: 1/alpha = max(1, max_i -dv_i / v_i) over the slacks and the
+        // multipliers (COMPUTE_ALPHA_QP's alpha = min(1, min_{dv_i<0} -v_i/dv_i)).  The slack
+        // candidates use the cached 1/t — one multiply and one max each, no selects; the multiplier
+        // candidates keep a running ratio n/d compared by cross-multiplication and cost one
+        // reciprocal per lane; the reciprocal of the result is taken once, after the reduction.
+        double ginv = 1.0;
+        double dn = 1.0, dd = -1.0;
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dlam_net[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -964,12 +970,10 @@ struct Wave : Algebra {
             Step s;
             con_step(q, dl[j], s);
             if (has_bound(j)) {
-                // COMPUTE_ALPHA_QP's running rule "if (a * dv > v) a = v / dv" with a = n / d, d < 0,
-                // compared by cross-multiplication: one reciprocal per lane instead of one per bound
                 if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
-                if (pn * s.dt_l < q.t_l * pd) { pn = q.t_l; pd = s.dt_l; }
                 if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
-                if (pn * s.dt_u < q.t_u * pd) { pn = q.t_u; pd = s.dt_u; }
+                ginv = fmax(ginv, -(s.dt_l * q.ti_l));
+                ginv = fmax(ginv, -(s.dt_u * q.ti_u));
                 s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
                 s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
                 s2 += s.dl_l * s.dt_l;
@@ -1008,12 +1012,11 @@ struct Wave : Algebra {
             for (int q = 0; q < 4; ++q) dza[q] = dl[q];
         }
         // the running values are negative ratios in (-1, 0]: the binding one is the largest
-        const double a_prim = pn * rcp(pd), a_dual = dn * rcp(dd);
-        // HPIPM steps with alpha = min(alpha_prim, alpha_dual): one reduction on max(a_prim, a_dual)
-        double am[1] = {fmax(a_prim, a_dual)}, as[2] = {s1, s2};
+        // HPIPM steps with alpha = min(alpha_prim, alpha_dual): one reduction on the larger inverse
+        double am[1] = {fmax(ginv, -(dd * rcp(dn)))}, as[2] = {s1, s2};
         x.rmax(am);
         x.rsum(as);
-        o.alpha = -am[0]; o.s1 = as[0]; o.s2 = as[1];
+        o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
         // the linear system's residual is only ever compared with thresholds: ballots
         o.lin_itref = FINAL ? x.gany(!(lin_g < c.itref_tol_g)) : false;
         o.lin_lq = FINAL ? x.gany(!(lin_g < c.lq_tol)) : false;
