@@ -415,22 +415,24 @@ struct Wave : Algebra {
         rg[1] = c.wg[1] * (z[1] - yref[4]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) rg[2 + q] = (isN ? c.we[q] : c.wg[2 + q]) * (z[2 + q] - yref[q]) - pim[q];
+        // Entries without a bound (stage N, the state bounds of stage 0) carry lam = 0, t = 1: their
+        // lam*t, Gamma and gamma are exact zeros, so only the two norm tests need the predicate.
+        // The norms themselves are only compared with tolerances ("max > tol" = "any > tol").
         double Gam[4], gam[4];
-        double pg = 0.0, pb = 0.0, pd = 0.0, pm = 0.0, ps = 0.0;
+        double pg = 0.0, pb = 0.0, ps = 0.0;
+        bool viol = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
             con_cached(j, q);
-            const bool hb = has_bound(j);
-            if (hb) {
-                rg[j] += q.lam_u - q.lam_l;
-                pd = amax(pd, q.rd_l); pd = amax(pd, q.rd_u);
-                pm = amax(pm, q.rm_l); pm = amax(pm, q.rm_u);
-                ps += q.rm_l;
-                ps += q.rm_u;
-            }
-            Gam[j] = hb ? con_Gamma(q) : 0.0;
-            gam[j] = hb ? con_gamma(q) : 0.0;
+            rg[j] += q.lam_u - q.lam_l;
+            viol = viol || (has_bound(j) && (fabs(q.rd_l) > c.res_d_max || fabs(q.rd_u) > c.res_d_max ||
+                                             fabs(fabs(q.rm_l) - c.tau_min) > c.res_m_max ||
+                                             fabs(fabs(q.rm_u) - c.tau_min) > c.res_m_max));
+            ps += q.rm_l;
+            ps += q.rm_u;
+            Gam[j] = con_Gamma(q);
+            gam[j] = con_gamma(q);
         }
         const double rb0 = cv[0] - zxn[0] + (ab.B00 * z[0] + ab.B01 * z[1] + (z[2] + ab.a * z[4]));
         const double rb1 = cv[1] - zxn[1] + (ab.B10 * z[0] + ab.B11 * z[1] + (z[3] + ab.b * z[4]));
@@ -449,8 +451,7 @@ struct Wave : Algebra {
         // HPIPM tests the four inf-norms against their tolerances; "max over lanes > tol" is "any
         // lane > tol" (|m - tau_min| > tol is monotone in m for m >= tau_min and false below), so
         // the four max-reductions collapse into one ballot.  Only mu needs a real reduction.
-        open = x.gany(pg > c.res_g_max || pb > c.res_b_max || pd > c.res_d_max ||
-                      fabs(pm - c.tau_min) > c.res_m_max);
+        open = x.gany(pg > c.res_g_max || pb > c.res_b_max || viol);
         double ns[1] = {ps};
         x.rsum(ns);
         musum = ns[0];
@@ -754,9 +755,12 @@ struct Wave : Algebra {
         Gain g;
         gain(P, ab, Gam[0], Gam[1], true, g);
         id0 = g.id0; l10 = g.l10; id1 = g.id1;
+        // (no masking: from stage N on B = 0 makes K an exact zero, and the gain of stage 0 only ever
+        //  multiplies dx_0 = 0 or enters quantities of stage 0 that nobody reads)
+        K00 = g.K00; K01 = g.K01; K02 = g.K02; K10 = g.K10; K11 = g.K11; K12 = g.K12;
+#ifdef MPC_SCAN_CHECK_P
         const bool kk = mid && !is0;
-        K00 = kk ? g.K00 : 0.0; K01 = kk ? g.K01 : 0.0; K02 = kk ? g.K02 : 0.0;
-        K10 = kk ? g.K10 : 0.0; K11 = kk ? g.K11 : 0.0; K12 = kk ? g.K12 : 0.0;
+#endif
         // --- a-posteriori check: P_k of the scan against one sequential Riccati step from P_{k+1} ---
         // Off by default: the lin_g acceptance test in iterate() subsumes it (an inaccurate P shows up
         // as a stationarity residual of the linear system) and it costs 3.5 % of the kernel.
@@ -880,7 +884,7 @@ struct Wave : Algebra {
             Con q;
             con_cached(j, q);
             con_correct(q, mode, dza[j], sigma_mu);
-            gam[j] = has_bound(j) ? con_gamma(q) : 0.0;
+            gam[j] = con_gamma(q);   // exactly 0 without a bound: both sides are -sigma_mu
         }
         const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
         const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
@@ -970,10 +974,17 @@ struct Wave : Algebra {
             Step s;
             con_step(q, dl[j], s);
             if (has_bound(j)) {
-                if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
-                if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
-                ginv = fmax(ginv, -(s.dt_l * q.ti_l));
-                ginv = fmax(ginv, -(s.dt_u * q.ti_u));
+                const double gl = s.dt_l * q.ti_l, gu = s.dt_u * q.ti_u;
+                ginv = fmax(ginv, -gl);
+                ginv = fmax(ginv, -gu);
+                if (FINAL) {
+                    if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
+                    if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
+                } else {
+                    // affine direction: dlam = -(1/t)(lam dt + lam t), so -dlam/lam = 1 + dt/t
+                    ginv = fmax(ginv, 1.0 + gl);
+                    ginv = fmax(ginv, 1.0 + gu);
+                }
                 s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
                 s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
                 s2 += s.dl_l * s.dt_l;
@@ -1013,7 +1024,7 @@ struct Wave : Algebra {
         }
         // the running values are negative ratios in (-1, 0]: the binding one is the largest
         // HPIPM steps with alpha = min(alpha_prim, alpha_dual): one reduction on the larger inverse
-        double am[1] = {fmax(ginv, -(dd * rcp(dn)))}, as[2] = {s1, s2};
+        double am[1] = {FINAL ? fmax(ginv, -(dd * rcp(dn))) : ginv}, as[2] = {s1, s2};
         x.rmax(am);
         x.rsum(as);
         o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
