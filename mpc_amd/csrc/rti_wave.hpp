@@ -244,6 +244,11 @@ struct Wave : Algebra {
     int wdiag = 0;               // MPC_DIAG_* bits raised inside the sweeps
     bool seq_now = false;        // SCAN build: use the sequential recursions (fallback of one iteration)
     mc_d2* mc = nullptr;         // this lane's column of the product cache (X::MCACHE)
+    // 1.0 where this stage has input bounds (k < N) / state bounds (0 < k < N), else 0.0.  Entries
+    // without a bound carry lam = 0, t = 1; scaling sigma*mu, the step length and the lam clamp by
+    // these factors keeps them there and makes every contribution of such an entry an exact zero,
+    // so the sweeps need no per-bound selects.
+    double fbu = 0.0, fbx = 0.0;
 
     struct State {
         int kk, diag;
@@ -255,7 +260,10 @@ struct Wave : Algebra {
     __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_, mc_d2* mc_ = nullptr)
         : Algebra(c_), x(x_), k(stage), N(c_.N), mc(mc_) {
         act = k <= N; mid = k < N; isN = k == N; is0 = k == 0;
+        fbu = mid ? 1.0 : 0.0;
+        fbx = (mid && !is0) ? 1.0 : 0.0;
     }
+    __device__ __forceinline__ double bf(int j) const { return j < 2 ? fbu : fbx; }
     __device__ __forceinline__ void mc_store(int level, const M3& M) const {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -387,19 +395,18 @@ struct Wave : Algebra {
             for (int j = 0; j < 4; ++j) {
                 Con q;
                 con_cached(j, q);
-                con_correct(q, mode, dza[j], sigma_mu);
+                con_correct(q, mode, dza[j], sigma_mu * bf(j));
                 Step s;
                 con_step(q, dz[j], s);
-                double ll = q.lam_l + alpha * s.dl_l, lu = q.lam_u + alpha * s.dl_u;
-                double tl = q.t_l + alpha * s.dt_l, tu = q.t_u + alpha * s.dt_u;
-                if (ll < c.lam_min) ll = c.lam_min;
-                if (lu < c.lam_min) lu = c.lam_min;
+                const double aj = alpha * bf(j), lmin = c.lam_min * bf(j);   // no bound: lam stays 0, t stays 1
+                double ll = q.lam_l + aj * s.dl_l, lu = q.lam_u + aj * s.dl_u;
+                double tl = q.t_l + aj * s.dt_l, tu = q.t_u + aj * s.dt_u;
+                if (ll < lmin) ll = lmin;
+                if (lu < lmin) lu = lmin;
                 if (tl < c.t_min) tl = c.t_min;
                 if (tu < c.t_min) tu = c.t_min;
-                if (has_bound(j)) {
-                    bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
-                    ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
-                }
+                bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
+                ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
             }
 #pragma unroll
             for (int q = 0; q < 5; ++q) z[q] = z[q] + alpha * dz[q];
@@ -883,8 +890,8 @@ struct Wave : Algebra {
         for (int j = 0; j < 4; ++j) {
             Con q;
             con_cached(j, q);
-            con_correct(q, mode, dza[j], sigma_mu);
-            gam[j] = con_gamma(q);   // exactly 0 without a bound: both sides are -sigma_mu
+            con_correct(q, mode, dza[j], sigma_mu * bf(j));
+            gam[j] = con_gamma(q);   // exactly 0 without a bound
         }
         const double q0 = P.p00 * rb[0] + P.p10 * rb[1] + P.p20 * rb[2];
         const double q1 = P.p10 * rb[0] + P.p11 * rb[1] + P.p21 * rb[2];
@@ -970,27 +977,26 @@ struct Wave : Algebra {
         for (int j = 0; j < 4; ++j) {
             Con q;
             con_cached(j, q);
-            if (FINAL) con_correct(q, mode, dza[j], sigma_mu);
+            if (FINAL) con_correct(q, mode, dza[j], sigma_mu * bf(j));
             Step s;
             con_step(q, dl[j], s);
-            if (has_bound(j)) {
-                const double gl = s.dt_l * q.ti_l, gu = s.dt_u * q.ti_u;
-                ginv = fmax(ginv, -gl);
-                ginv = fmax(ginv, -gu);
-                if (FINAL) {
-                    if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
-                    if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
-                } else {
-                    // affine direction: dlam = -(1/t)(lam dt + lam t), so -dlam/lam = 1 + dt/t
-                    ginv = fmax(ginv, 1.0 + gl);
-                    ginv = fmax(ginv, 1.0 + gu);
-                }
-                s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
-                s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
-                s2 += s.dl_l * s.dt_l;
-                s2 += s.dl_u * s.dt_u;
-                dlam_net[j] = s.dl_u - s.dl_l;
+            // (no has_bound guard: without a bound dlam = 0 exactly and the slack ratios are scaled to 0)
+            const double gl = (s.dt_l * q.ti_l) * bf(j), gu = (s.dt_u * q.ti_u) * bf(j);
+            ginv = fmax(ginv, -gl);
+            ginv = fmax(ginv, -gu);
+            if (FINAL) {
+                if (dn * s.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = s.dl_l; }
+                if (dn * s.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = s.dl_u; }
+            } else {
+                // affine direction: dlam = -(1/t)(lam dt + lam t), so -dlam/lam = 1 + dt/t
+                ginv = fmax(ginv, 1.0 + gl);
+                ginv = fmax(ginv, 1.0 + gu);
             }
+            s1 += q.lam_l * s.dt_l + q.t_l * s.dl_l;
+            s1 += q.lam_u * s.dt_u + q.t_u * s.dl_u;
+            s2 += s.dl_l * s.dt_l;
+            s2 += s.dl_u * s.dt_u;
+            dlam_net[j] = s.dl_u - s.dl_l;
         }
         if (FINAL) {
 #pragma unroll
