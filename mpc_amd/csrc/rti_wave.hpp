@@ -386,33 +386,10 @@ struct Wave : Algebra {
         rb[0] = rb[1] = rb[2] = 0.0;
     }
 
-    // ---- BU: variable update + residuals (all stages at once) + Riccati factorisation with
-    //      the affine right-hand side (sequential over stages).  Lane::sweep_bu.
-    template <bool FIRST>
-    __device__ __forceinline__ void bu(int mode, double sigma_mu, double alpha, double& musum, bool& open) {
-        if (!FIRST) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Con q;
-                con_cached(j, q);
-                con_correct(q, mode, dza[j], sigma_mu * bf(j));
-                Step s;
-                con_step(q, dz[j], s);
-                const double aj = alpha * bf(j), lmin = c.lam_min * bf(j);   // no bound: lam stays 0, t stays 1
-                double ll = q.lam_l + aj * s.dl_l, lu = q.lam_u + aj * s.dl_u;
-                double tl = q.t_l + aj * s.dt_l, tu = q.t_u + aj * s.dt_u;
-                if (ll < lmin) ll = lmin;
-                if (lu < lmin) lu = lmin;
-                if (tl < c.t_min) tl = c.t_min;
-                if (tu < c.t_min) tu = c.t_min;
-                bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
-                ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q) z[q] = z[q] + alpha * dz[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pi[q] = pi[q] + alpha * dpi[q];
-        }
+    // ---- BU: residuals at the current point (all stages at once) + Riccati factorisation with the
+    //      affine right-hand side.  Lane::sweep_bu without its variable update, which happens at
+    //      the end of the accepted corrector pass (fw<true>) where the steps are still in registers.
+    __device__ __forceinline__ void bu(double& musum, bool& open) {
         // --- residuals at the new point ---
         double pim[3] = {pi[0], pi[1], pi[2]}, zxn[3] = {z[2], z[3], z[4]};
         x.prev(pim);
@@ -957,9 +934,15 @@ struct Wave : Algebra {
     struct FwdOut {
         double alpha, s1, s2;               // min(alpha_prim, alpha_dual), the two mu_aff sums
         bool lin_itref, lin_lq, lin_scan;   // lin_g >= itref_tol_g / lq_tol / scan_tol_lin (FINAL only)
+        bool redo_centering;                // FINAL: mu would grow -> redo the corrector as pure centering
+        bool accepted;                      // FINAL: the step was taken (variables updated)
     };
+    // FINAL: the corrector pass.  It also decides, from the reductions it has just made, whether
+    // the direction is the one to take (HPIPM's conditional predictor-corrector test; the scan
+    // acceptance test when `may_retry`), and if so performs the variable update right here.
     template <bool FINAL>
-    __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o) {
+    __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o, double musum = 0.0, double mu_aff0 = 0.0,
+                                       bool may_retry = false) {
         double nx0 = 0.0, nx1 = 0.0, nx2 = 0.0;   // dx_{k+1}, produced by the lane of stage k
         double dl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (SCAN && !seq_now) fwd_scan(nx0, nx1, nx2, dl);
@@ -973,6 +956,7 @@ struct Wave : Algebra {
         double dn = 1.0, dd = -1.0;
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dlam_net[4] = {0.0, 0.0, 0.0, 0.0};
+        Step st[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
@@ -980,6 +964,7 @@ struct Wave : Algebra {
             if (FINAL) con_correct(q, mode, dza[j], sigma_mu * bf(j));
             Step s;
             con_step(q, dl[j], s);
+            st[j] = s;
             // (no has_bound guard: without a bound dlam = 0 exactly and the slack ratios are scaled to 0)
             const double gl = (s.dt_l * q.ti_l) * bf(j), gu = (s.dt_u * q.ti_u) * bf(j);
             ginv = fmax(ginv, -gl);
@@ -1038,16 +1023,43 @@ struct Wave : Algebra {
         o.lin_itref = FINAL ? x.gany(!(lin_g < c.itref_tol_g)) : false;
         o.lin_lq = FINAL ? x.gany(!(lin_g < c.lq_tol)) : false;
         o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
+        o.redo_centering = false;
+        o.accepted = false;
+        if (FINAL) {
+            const double alpha = o.alpha;
+            if (mode == 1) {
+                const double mu_aff1 = (musum + alpha * o.s1 + (alpha * alpha) * o.s2) * nc_inv();
+                o.redo_centering = mu_aff1 > 2.0 * mu_aff0;
+            }
+            o.accepted = !o.redo_centering && !(may_retry && o.lin_scan);
+            if (o.accepted) {
+                // COMPUTE step: variables move by the damped step length (d_ocp_qp_ipm_solve)
+                double a_upd = alpha;
+                if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double aj = a_upd * bf(j), lmin = c.lam_min * bf(j);   // no bound: lam stays 0, t stays 1
+                    double ll = bn.lam[j] + aj * st[j].dl_l, lu = bn.lam[4 + j] + aj * st[j].dl_u;
+                    double tl = bn.t[j] + aj * st[j].dt_l, tu = bn.t[4 + j] + aj * st[j].dt_u;
+                    if (ll < lmin) ll = lmin;
+                    if (lu < lmin) lu = lmin;
+                    if (tl < c.t_min) tl = c.t_min;
+                    if (tu < c.t_min) tu = c.t_min;
+                    bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
+                    ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q) z[q] = z[q] + a_upd * dz[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pi[q] = pi[q] + a_upd * dpi[q];
+            }
+        }
     }
 
     // ---- the RTI step (Lane::begin / cont / iterate) ----
     __device__ __forceinline__ double nc_inv() const { return 1.0 / (4 + 8 * (c.N - 1)); }
     __device__ __forceinline__ void begin(State& s) {
-        // with a zero step and alpha = 0 the update half of BU is the identity (cold-start values
-        // are far above the lam/t clamps), so the first residual + factorisation pass shares the
-        // code of the per-iteration one: one copy of the largest block keeps the kernel within
-        // the instruction cache
-        bu<false>(0, 0.0, 0.0, s.musum, s.open);
+        bu(s.musum, s.open);
         s.mu = s.musum * nc_inv();
         s.alpha = 1.0;
         s.kk = 0;
@@ -1100,22 +1112,18 @@ struct Wave : Algebra {
 #pragma nounroll
             for (;;) {
                 bw(mode, sigma_mu);
-                fw<true>(mode, sigma_mu, fc);
+                fw<true>(mode, sigma_mu, fc, s.musum, mu_aff0, SCAN && attempt == 0);
                 alpha = fc.alpha;
-                if (mode == 2) break;
-                const double mu_aff1 = (s.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
-                if (!(mu_aff1 > 2.0 * mu_aff0)) break;
+                if (!fc.redo_centering) break;
                 mode = 2;
             }
-            if (!SCAN || attempt == 1 || !fc.lin_scan) break;
+            if (fc.accepted) break;
         }
         seq_now = false;
         if (fc.lin_itref) s.diag |= MPC_DIAG_ITREF;
         if (fc.lin_lq) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
-        double a_upd = alpha;
-        if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
-        bu<false>(mode, sigma_mu, a_upd, s.musum, s.open);
+        bu(s.musum, s.open);
         s.mu = s.musum * nci;
         ++s.kk;
     }
