@@ -678,3 +678,41 @@ def test_non_finite_inputs_stay_inside_their_instance(N):
     assert np.array_equal(ud[ok], uc[ok]) and np.array_equal(xd[ok], xc[ok])
     assert (rd["status"][bad] != 0).all()
     clean.close(); dirty.close()
+
+
+def test_one_handle_per_thread_concurrently(oracle):
+    """The C-ABI's threading contract: no global state, one handle per thread.
+    Four host threads drive four handles (different variants and batch sizes) at the same time
+    (ctypes releases the GIL during the calls); every result equals the oracle's."""
+    import threading
+    jobs = [("mobile_robot", 300), ("mobile_robot_25", 257), ("park", 130), ("mobile_robot_18", 1)]
+    errors, results = [], {}
+
+    def work(name, B):
+        try:
+            sp, wl = workload.make(name, B)
+            solver = capi.BatchSolver(sp, B)
+            out = []
+            for t in range(6):
+                x0, yref, yref_e = wl.tick(t)
+                rg = solver.solve(x0, yref, yref_e)
+                xg, ug, _ = solver.get(B, want_pi=False)
+                out.append((rg, xg, ug))
+            solver.close()
+            results[name] = (sp, wl, out)
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for th in threads: th.start()
+    for th in threads: th.join(timeout=120)
+    assert not errors, errors
+    for name, B in jobs:
+        sp, wl, out = results[name]
+        xo = uo = None
+        for t, (rg, xg, ug) in enumerate(out):
+            x0, yref, yref_e = wl.tick(t)
+            ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
+            xo, uo = ro["xtraj"], ro["utraj"]
+            rg["xtraj"], rg["utraj"] = xg, ug
+            _compare(ro, rg, B, min_same=0.99)
