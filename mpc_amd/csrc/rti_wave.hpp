@@ -716,7 +716,16 @@ struct Wave : Algebra {
                 W.m[5] = (Xm.m[2] * Xm.m[3] - Xm.m[0] * Xm.m[5]) * idet;
                 W.m[8] = (Xm.m[0] * Xm.m[4] - Xm.m[1] * Xm.m[3]) * idet;
                 // J12 = A1^T (J2 W) A1 + J1
-                const M3 U = m3_mul(m3_mul(Jm, W), A);
+                // J2 W = (J2^-1 + C1)^-1 is symmetric: 6 of its 9 entries are computed, 3 mirrored
+                M3 JW;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        JW.m[3 * i + j] = Jm.m[3 * i] * W.m[j] + Jm.m[3 * i + 1] * W.m[3 + j] + Jm.m[3 * i + 2] * W.m[6 + j];
+                        JW.m[3 * j + i] = JW.m[3 * i + j];
+                    }
+                const M3 U = m3_mul(JW, A);
                 J[0] += A.m[0] * U.m[0] + A.m[3] * U.m[3] + A.m[6] * U.m[6];
                 J[1] += A.m[1] * U.m[0] + A.m[4] * U.m[3] + A.m[7] * U.m[6];
                 J[2] += A.m[1] * U.m[1] + A.m[4] * U.m[4] + A.m[7] * U.m[7];
