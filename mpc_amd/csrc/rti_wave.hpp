@@ -671,9 +671,86 @@ struct Wave : Algebra {
             for (int i = 0; i < 6; ++i) { C[i] = 0.0; J[i] = 0.0; }
             J[0] = c.we[0] + c.reg_prim; J[2] = c.we[1] + c.reg_prim; J[5] = c.we[2] + c.reg_prim;
         }
-        // --- suffix scan ---
+        // --- suffix scan, first level (distance 1) on the structured single-stage elements:
+        //     A = e I + a E02 + b E12 (e = 1, or 0 from stage N on), J diagonal.  The same
+        //     combination as below with the zeros and ones written out: 12 instead of 21 values
+        //     shuffled and about 80 multiply-adds fewer.
+        {
+            const double e1 = fbu, a1 = ab.a, b1 = ab.b;
+            double f[12] = {e1, a1, b1, C[0], C[1], C[2], C[3], C[4], C[5], J[0], J[2], J[5]};
+            x.down(f, 1);
+            if (!GUARD || k + 1 <= N) {
+                const double e2 = f[0], a2 = f[1], b2 = f[2];
+                const double C2[6] = {f[3], f[4], f[5], f[6], f[7], f[8]};
+                const double j20 = f[9], j21 = f[10], j22 = f[11];
+                M3 Cm;
+                Cm.m[0] = C[0]; Cm.m[1] = C[1]; Cm.m[2] = C[3]; Cm.m[3] = C[1]; Cm.m[4] = C[2]; Cm.m[5] = C[4]; Cm.m[6] = C[3]; Cm.m[7] = C[4]; Cm.m[8] = C[5];
+                M3 Xm;   // I + C1 diag(j2)
 #pragma unroll
-        for (int d = 1; d < GW; d *= 2) {
+                for (int i = 0; i < 3; ++i) { Xm.m[3 * i] = Cm.m[3 * i] * j20; Xm.m[3 * i + 1] = Cm.m[3 * i + 1] * j21; Xm.m[3 * i + 2] = Cm.m[3 * i + 2] * j22; }
+                Xm.m[0] += 1.0; Xm.m[4] += 1.0; Xm.m[8] += 1.0;
+                M3 W;
+                const double c00 = Xm.m[4] * Xm.m[8] - Xm.m[5] * Xm.m[7];
+                const double c01 = Xm.m[5] * Xm.m[6] - Xm.m[3] * Xm.m[8];
+                const double c02 = Xm.m[3] * Xm.m[7] - Xm.m[4] * Xm.m[6];
+                const double idet = rcp(Xm.m[0] * c00 + Xm.m[1] * c01 + Xm.m[2] * c02);
+                W.m[0] = c00 * idet; W.m[3] = c01 * idet; W.m[6] = c02 * idet;
+                W.m[1] = (Xm.m[2] * Xm.m[7] - Xm.m[1] * Xm.m[8]) * idet;
+                W.m[4] = (Xm.m[0] * Xm.m[8] - Xm.m[2] * Xm.m[6]) * idet;
+                W.m[7] = (Xm.m[1] * Xm.m[6] - Xm.m[0] * Xm.m[7]) * idet;
+                W.m[2] = (Xm.m[1] * Xm.m[5] - Xm.m[2] * Xm.m[4]) * idet;
+                W.m[5] = (Xm.m[2] * Xm.m[3] - Xm.m[0] * Xm.m[5]) * idet;
+                W.m[8] = (Xm.m[0] * Xm.m[4] - Xm.m[1] * Xm.m[3]) * idet;
+                // JW = diag(j2) W, symmetric
+                M3 JW;
+                JW.m[0] = j20 * W.m[0];
+                JW.m[3] = j21 * W.m[3]; JW.m[4] = j21 * W.m[4];
+                JW.m[6] = j22 * W.m[6]; JW.m[7] = j22 * W.m[7]; JW.m[8] = j22 * W.m[8];
+                JW.m[1] = JW.m[3]; JW.m[2] = JW.m[6]; JW.m[5] = JW.m[7];
+                // U = JW A1
+                M3 U;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    U.m[3 * i] = JW.m[3 * i] * e1;
+                    U.m[3 * i + 1] = JW.m[3 * i + 1] * e1;
+                    U.m[3 * i + 2] = JW.m[3 * i] * a1 + JW.m[3 * i + 1] * b1 + JW.m[3 * i + 2] * e1;
+                }
+                // J12 = J1 + A1^T U
+                const double jd0 = J[0], jd1 = J[2], jd2 = J[5];
+                J[0] = jd0 + e1 * U.m[0];
+                J[1] = e1 * U.m[3];
+                J[2] = jd1 + e1 * U.m[4];
+                J[3] = a1 * U.m[0] + b1 * U.m[3] + e1 * U.m[6];
+                J[4] = a1 * U.m[1] + b1 * U.m[4] + e1 * U.m[7];
+                J[5] = jd2 + (a1 * U.m[2] + b1 * U.m[5] + e1 * U.m[8]);
+                // G = A2 W
+                M3 G;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    G.m[j] = e2 * W.m[j] + a2 * W.m[6 + j];
+                    G.m[3 + j] = e2 * W.m[3 + j] + b2 * W.m[6 + j];
+                    G.m[6 + j] = e2 * W.m[6 + j];
+                }
+                const M3 T = m3_mul(G, Cm);
+                // C12 = T A2^T + C2
+                C[0] = C2[0] + (T.m[0] * e2 + T.m[2] * a2);
+                C[1] = C2[1] + (T.m[3] * e2 + T.m[5] * a2);
+                C[2] = C2[2] + (T.m[4] * e2 + T.m[5] * b2);
+                C[3] = C2[3] + (T.m[6] * e2 + T.m[8] * a2);
+                C[4] = C2[4] + (T.m[7] * e2 + T.m[8] * b2);
+                C[5] = C2[5] + T.m[8] * e2;
+                // A12 = G A1
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    A.m[3 * i] = G.m[3 * i] * e1;
+                    A.m[3 * i + 1] = G.m[3 * i + 1] * e1;
+                    A.m[3 * i + 2] = G.m[3 * i] * a1 + G.m[3 * i + 1] * b1 + G.m[3 * i + 2] * e1;
+                }
+            }
+        }
+        // --- the remaining levels on full elements ---
+#pragma unroll
+        for (int d = 2; d < GW; d *= 2) {
             M3 A2;
             double C2[6], J2[6];
             if (2 * d < GW) {
