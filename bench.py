@@ -26,12 +26,12 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v11):
+# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v12):
 # FETCH_SIZE 2.909e5 KiB x 2 (gfx950 correction of the guide) + WRITE_SIZE 3.69e5 KiB
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 0.97e9
 # FP64 flops one k_wave launch (65536 x N=50, warm ticks) EXECUTES, from the SQ counters in
-# profiles/r01/v11_pmc_sq.csv: (2 x 9.31e8 FMA + 5.37e8 MUL + 2.68e8 ADD wave-instructions) x 64 lanes
-MEASURED_FP64_FLOP_PER_LAUNCH = 1.71e11
+# profiles/r01/v12_pmc_sq.csv: (2 x 8.58e8 FMA + 5.31e8 MUL + 2.61e8 ADD wave-instructions) x 64 lanes
+MEASURED_FP64_FLOP_PER_LAUNCH = 1.60e11
 
 
 def algorithmic_bytes_per_solve(N):
@@ -197,7 +197,7 @@ def main():
             out["roofline_fp64"]["executed_achieved"] = ex_tf
             out["roofline_fp64"]["executed_frac"] = ex_tf / FP64_VECTOR_PEAK_TFLOPS
             out["roofline_fp64"]["executed_note"] = ("FP64 flops the launch executes by the SQ instruction counters (rocprofv3 --pmc, "
-                                                     "profiles/r01/v11_pmc_sq.csv; all 64 lanes counted, idle stages and scan overhead included)")
+                                                     "profiles/r01/v12_pmc_sq.csv; all 64 lanes counted, idle stages and scan overhead included)")
         # ---- batch=1 latency (second half of the metric) ----
         if not args.no_latency:
             sp1, wl1 = workload.make(args.variant, 1)
