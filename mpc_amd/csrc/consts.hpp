@@ -7,23 +7,36 @@
 #include <string.h>
 
 #include "../../include/mpc_batch.h"
+#include "../../include/mpc_hpipm_args.h"
 #include "rti_core.hpp"
 
 namespace mpc {
 
-inline int spec_valid(const mpc_ocp_spec_t* s) {
-    if (!s) return 0;
-    if (s->N < 1 || s->N > MPC_MAX_N) return 0;
-    if (!(s->Ts > 0.0)) return 0;
-    if (s->qp_iter_max < 0 || s->sqp_max_iter < 1) return 0;
-    for (int i = 0; i < 5; ++i) if (!(s->W[i] > 0.0)) return 0;
-    for (int i = 0; i < 3; ++i) if (!(s->W_e[i] > 0.0)) return 0;
+// Acceptance tests of the wave model's parallel scans (rti_wave.hpp): fixed, part of the solver's
+// definition (they decide when an iteration is redone with the sequential recursions).
+constexpr double kScanTolP = 1e-11;     // relative residual of the Riccati equation (MPC_SCAN_CHECK_P builds only)
+constexpr double kScanTolLin = 1e-8;    // stationarity residual of the corrector's linear system (absolute)
+
+// Returns nullptr when the spec is acceptable, else what is wrong with it.
+inline const char* spec_problem(const mpc_ocp_spec_t* s) {
+    if (!s) return "spec is NULL";
+    if (s->N < 1 || s->N > MPC_MAX_N) return "N out of range [1, MPC_MAX_N]";
+    if (!(s->Ts > 0.0) || !(s->Ts < 1e3)) return "Ts must be positive and finite";
+    if (!(s->L >= 0.0) || !(s->L < 1e3)) return "L must be 0 (the generated literals) or a positive finite wheelbase";
+    if (s->qp_iter_max < 0 || s->sqp_max_iter < 1) return "qp_iter_max must be >= 0 and sqp_max_iter >= 1";
+    // Only the mode the reference uses is implemented (and even that one is parity unpinned):
+    // SPEED / SPEED_ABS use split steps or the absolute form, ROBUST a different factorisation.
+    if (s->hpipm_mode != MPC_HPIPM_BALANCE) return "hpipm_mode: only MPC_HPIPM_BALANCE is implemented";
+    if (s->sqp_max_iter > 1 && !(s->nlp_tol > 0.0 && s->nlp_tol < 1e3)) return "nlp_tol must be positive and finite when sqp_max_iter > 1";
+    for (int i = 0; i < 5; ++i) if (!(s->W[i] > 0.0) || !(s->W[i] < 1e300)) return "W must be positive and finite";
+    for (int i = 0; i < 3; ++i) if (!(s->W_e[i] > 0.0) || !(s->W_e[i] < 1e300)) return "W_e must be positive and finite";
     for (int i = 0; i < 2; ++i) {
-        if (!(s->lbu[i] < s->ubu[i])) return 0;
-        if (!(s->lbx[i] < s->ubx[i])) return 0;
+        if (!(s->lbu[i] < s->ubu[i])) return "lbu must be below ubu";
+        if (!(s->lbx[i] < s->ubx[i])) return "lbx must be below ubx";
     }
-    return 1;
+    return nullptr;
 }
+inline int spec_valid(const mpc_ocp_spec_t* s) { return spec_problem(s) == nullptr; }
 
 inline Consts make_consts(const mpc_ocp_spec_t& s) {
     Consts c;
@@ -51,24 +64,20 @@ inline Consts make_consts(const mpc_ocp_spec_t& s) {
     }
     c.lb[0] = s.lbu[0]; c.lb[1] = s.lbu[1]; c.lb[2] = s.lbx[0]; c.lb[3] = s.lbx[1];
     c.ub[0] = s.ubu[0]; c.ub[1] = s.ubu[1]; c.ub[2] = s.ubx[0]; c.ub[3] = s.ubx[1];
-    // HPIPM modes (x_ocp_qp_ipm.c, OCP_QP_IPM_ARG_SET_DEFAULT)
-    c.mu0 = 1e1;
-    c.alpha_min = 1e-12;
-    c.res_g_max = 1e-6; c.res_b_max = 1e-8; c.res_d_max = 1e-8; c.res_m_max = 1e-8;
-    c.reg_prim = 1e-15;
-    c.lam_min = 1e-16; c.t_min = 1e-16; c.tau_min = 1e-16;
-    c.thr0 = 1e-1;
-    if (s.hpipm_mode == MPC_HPIPM_SPEED || s.hpipm_mode == MPC_HPIPM_SPEED_ABS) {
-        c.res_g_max = c.res_b_max = c.res_d_max = 1e0;
-    } else if (s.hpipm_mode == MPC_HPIPM_ROBUST) {
-        c.mu0 = 1e2;
-    }
+    // HPIPM arguments of the reference's mode (include/mpc_hpipm_args.h) + acados' qp_iter_max
+    c.mu0 = MPC_IPM_MU0;
+    c.alpha_min = MPC_IPM_ALPHA_MIN;
+    c.res_g_max = MPC_IPM_RES_G_MAX; c.res_b_max = MPC_IPM_RES_B_MAX;
+    c.res_d_max = MPC_IPM_RES_D_MAX; c.res_m_max = MPC_IPM_RES_M_MAX;
+    c.reg_prim = MPC_IPM_REG_PRIM;
+    c.lam_min = MPC_IPM_LAM_MIN; c.t_min = MPC_IPM_T_MIN; c.tau_min = MPC_IPM_TAU_MIN;
+    c.thr0 = MPC_IPM_THR0;
     c.itref_tol_g = c.res_g_max;
-    c.lq_tol = 1e-5;
+    c.lq_tol = MPC_IPM_LQ_SWITCH_TOL;
     c.sqp = s.sqp_max_iter > 1 ? 1 : 0;
     c.nlp_tol = s.nlp_tol;
-    c.scan_tol_P = getenv("MPC_SCAN_TOL_P") ? atof(getenv("MPC_SCAN_TOL_P")) : 1e-11;
-    c.scan_tol_lin = getenv("MPC_SCAN_TOL_LIN") ? atof(getenv("MPC_SCAN_TOL_LIN")) : 1e-8;
+    c.scan_tol_P = kScanTolP;
+    c.scan_tol_lin = kScanTolLin;
     return c;
 }
 

@@ -393,9 +393,11 @@ struct Wave : Algebra {
         rb[0] = rb[1] = rb[2] = 0.0;
     }
 
-    // ---- BU: residuals at the current point (all stages at once) + Riccati factorisation with the
-    //      affine right-hand side.  Lane::sweep_bu without its variable update, which happens at
-    //      the end of the accepted corrector pass (fw<true>) where the steps are still in registers.
+    // ---- BU: residuals at the current point (all stages at once) and HPIPM's exit test.
+    //      Lane::sweep_bu without its variable update (which happens at the end of the accepted
+    //      corrector pass, fw<true>, where the steps are still in registers) and without the
+    //      factorisation: that is the head of the NEXT iteration (factor_now), so the iteration
+    //      that meets the exit test does not pay for a Riccati scan nobody uses.
     __device__ __forceinline__ void bu(double& musum, bool& open) {
         // --- residuals at the new point ---
         double pim[3] = {pi[0], pi[1], pi[2]}, zxn[3] = {z[2], z[3], z[4]};
@@ -409,7 +411,6 @@ struct Wave : Algebra {
         // Entries without a bound (stage N, the state bounds of stage 0) carry lam = 0, t = 1: their
         // lam*t, Gamma and gamma are exact zeros, so only the two norm tests need the predicate.
         // The norms themselves are only compared with tolerances ("max > tol" = "any > tol").
-        double Gam[4], gam[4];
         double pg = 0.0, pb = 0.0, ps = 0.0;
         bool viol = false;
 #pragma unroll
@@ -422,8 +423,6 @@ struct Wave : Algebra {
                                              fabs(fabs(q.rm_u) - c.tau_min) > c.res_m_max));
             ps += q.rm_l;
             ps += q.rm_u;
-            Gam[j] = con_Gamma(q);
-            gam[j] = con_gamma(q);
         }
         const double rb0 = cv[0] - zxn[0] + (ab.B00 * z[0] + ab.B01 * z[1] + (z[2] + ab.a * z[4]));
         const double rb1 = cv[1] - zxn[1] + (ab.B10 * z[0] + ab.B11 * z[1] + (z[3] + ab.b * z[4]));
@@ -446,7 +445,19 @@ struct Wave : Algebra {
         double ns[1] = {ps};
         x.rsum(ns);
         musum = ns[0];
+    }
 
+    // Barrier terms of the current point (exact zeros for entries without a bound: lam = 0, t = 1)
+    // and the Riccati factorisation with the affine right-hand side: the head of an IPM iteration.
+    __device__ __forceinline__ void factor_now() {
+        double Gam[4], gam[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Con q;
+            con_cached(j, q);
+            Gam[j] = con_Gamma(q);
+            gam[j] = con_gamma(q);
+        }
         factor(Gam, gam);
     }
 
@@ -1187,7 +1198,9 @@ struct Wave : Algebra {
         // once with the sequential recursions.  A loop, not two inlined copies (code size).
 #pragma nounroll
         for (int attempt = 0; attempt < 2; ++attempt) {
-            if (attempt == 1) {
+            if (attempt == 0) {
+                factor_now();
+            } else {
                 wdiag |= MPC_DIAG_SCAN_FALLBACK;
                 seq_now = true;
                 refactor_seq();
