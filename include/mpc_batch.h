@@ -23,7 +23,7 @@ extern "C" {
 #define MPC_NX 3 /* x, y, psi          (src/c_generated_code/acados_solver_mobile_robot.h NX) */
 #define MPC_NU 2 /* v, delta           (… NU) */
 #define MPC_NY 5 /* [x y psi v delta]  (… NY) */
-#define MPC_MAX_N 128 /* largest horizon a handle accepts (reference max is 80) */
+#define MPC_MAX_N 127 /* largest horizon a handle accepts (reference max is 80) */
 
 /* acados return codes reproduced per instance
  * (acados/utils/types.h; used at src/optimizer.cpp:290-293). */
@@ -170,12 +170,16 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 
 /* Per-instance diagnostic bits of the last solve (host pointer diag [B]); 0 on every workload the
- * tests measure.  No counterpart in the reference: they record where this solver's arithmetic
- * would have left HPIPM's path (deviations).
- *   1  HPIPM's corrector iterative refinement would have run (not performed here)
- *   2  HPIPM's lq_fact = 1 switch to the LQ factorisation would have fired (not performed here)
- *   4  wave model: a parallel Riccati scan failed its a-posteriori check against the Riccati
- *      equation and that factorisation was redone with the sequential recursion */
+ * bench measures.  No counterpart in the reference: they record where this solver's arithmetic
+ * left, or would have left, HPIPM's path (deviations).
+ *   1  the stationarity residual of the corrector's linear system was not below res_g_max:
+ *      HPIPM's corrector iterative refinement (itref_corr_max = 2) applies
+ *   2  that residual was not below 1e-5: HPIPM's lq_fact = 1 switch to the LQ factorisation
+ *      would have fired (not performed here)
+ *   4  wave model: the same residual was not below 1e-8 (absolute, fixed: kScanTolLin in
+ *      mpc_amd/csrc/consts.hpp) after an iteration computed with the parallel scans, and the
+ *      iteration's direction was recomputed with the sequential recursions inside the kernel.
+ *      (A direction whose residual is below 1e-8 is accepted without further checks.) */
 #define MPC_DIAG_ITREF 1
 #define MPC_DIAG_LQ 2
 #define MPC_DIAG_SCAN_FALLBACK 4
@@ -183,12 +187,12 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
 
 /* Execution model of the solve kernels (no counterpart in the reference; results agree to
  * rounding, ~1e-13, across models).  AUTO = WAVE when it applies, else LANE.
- *   LANE     one OCP per lane, IPM workspace in HBM (any N <= MPC_MAX_N, full SQP);
+ *   LANE     one OCP per lane, IPM workspace in HBM (allocated on the first solve that uses it);
  *   WAVE     one OCP per wavefront (lane = stage), workspace in registers, Riccati recursion
- *            and the two substitutions as parallel scans (N <= 127; 64 <= N uses a 128-thread
+ *            and the two substitutions as parallel scans (64 <= N uses a 128-thread
  *            workgroup per OCP);
  *   WAVE_SEQ same mapping with sequential recursions (cross-check of the scans).
- * A model that does not apply to the handle's spec falls back to LANE.  The environment
+ * The environment
  * variable MPC_MODEL=lane|wave|waveseq sets the default of handles left on AUTO. */
 #define MPC_MODEL_AUTO 0
 #define MPC_MODEL_LANE 1
@@ -200,8 +204,17 @@ int mpc_batch_set_model(mpc_batch_t* h, int model);
  * (hipEvents on the handle's stream around the device work), horizon,
  * capacity, and the last HIP error string of this handle. */
 double mpc_batch_last_kernel_ms(mpc_batch_t* h);
-double mpc_batch_last_phase0_ms(mpc_batch_t* h); /* device time of the dense first k_phase launch */
-int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8); /* live instances entering phases 1..7 of the last solve */
+double mpc_batch_last_phase0_ms(mpc_batch_t* h); /* device time of the dominant solve kernel (k_wave / first k_phase) */
+/* Test hook, no counterpart in the reference (its QP data stay inside libacados): what the
+ * preparation phase hands to the QP at the capsules' CURRENT iterate, for yref / yref_e given
+ * as host arrays: out [B][N+1][24] (host) = a, b, B00, B10, B20, B01, B11, B21 (the non-trivial
+ * entries of A_k = [[1,0,a],[0,1,b],[0,0,1]] and of B_k, row-major names), b_k = phi(x_k,u_k) -
+ * x_{k+1} (3), LINEAR_LS gradient in [v, delta, x, y, psi] order (5), BGH residuals lb - z (4)
+ * and z - ub (4) on (v, delta, x, y); entries a stage does not have are 0. */
+int mpc_batch_debug_linearize(mpc_batch_t* h, int B, const double* yref, const double* yref_e, double* out);
+/* Device memory the handle holds right now, in bytes (capsules + what the calls made so far
+ * have allocated: host-pointer staging, lane-model workspace, tracker). */
+size_t mpc_batch_device_bytes(const mpc_batch_t* h);
 int mpc_batch_horizon(const mpc_batch_t* h);
 int mpc_batch_capacity(const mpc_batch_t* h);
 const char* mpc_batch_last_error(const mpc_batch_t* h);

@@ -24,7 +24,7 @@ EXPORTS = (
     "mpc_spec_variant", "mpc_batch_create", "mpc_batch_solve", "mpc_batch_solve_device",
     "mpc_batch_reset", "mpc_batch_get", "mpc_batch_sim_step", "mpc_batch_free",
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
-    "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_phase_counts", "mpc_batch_last_phase0_ms",
+    "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_linearize", "mpc_batch_device_bytes", "mpc_batch_last_phase0_ms",
     "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model", "mpc_batch_get_diag",
     "mpc_batch_shift", "mpc_batch_track_set_shift",
 )
@@ -76,7 +76,9 @@ def lib():
     L.mpc_batch_free.restype = None
     L.mpc_batch_last_kernel_ms.argtypes = [_vp]
     L.mpc_batch_last_kernel_ms.restype = ctypes.c_double
-    L.mpc_batch_debug_phase_counts.argtypes = [_vp, _ip]
+    L.mpc_batch_debug_linearize.argtypes = [_vp, ctypes.c_int, _dp, _dp, _dp]
+    L.mpc_batch_device_bytes.argtypes = [_vp]
+    L.mpc_batch_device_bytes.restype = ctypes.c_size_t
     L.mpc_batch_last_phase0_ms.argtypes = [_vp]
     L.mpc_batch_last_phase0_ms.restype = ctypes.c_double
     L.mpc_batch_get_sqp.argtypes = [_vp, ctypes.c_int, _ip, _dp]
@@ -244,10 +246,18 @@ class BatchSolver:
         self._check(lib().mpc_batch_sim_step(self._h, x.shape[0], _p(x), _p(u)), "mpc_batch_sim_step")
         return x
 
-    def phase_counts(self):
-        out = np.zeros(8, np.int32)
-        self._check(lib().mpc_batch_debug_phase_counts(self._h, _pi(out)), "mpc_batch_debug_phase_counts")
-        return out
+    def debug_linearize(self, yref, yref_e):
+        """QP data of the preparation phase at the capsules' current iterate (test hook):
+        dict(ab [B,N+1,8], b [B,N+1,3], g [B,N+1,5], d [B,N+1,8])."""
+        yref = np.ascontiguousarray(yref, np.float64)
+        yref_e = np.ascontiguousarray(yref_e, np.float64)
+        B = yref.shape[0]
+        out = np.zeros((B, self.N + 1, 24))
+        self._check(lib().mpc_batch_debug_linearize(self._h, B, _p(yref), _p(yref_e), _p(out)), "mpc_batch_debug_linearize")
+        return dict(ab=out[:, :, 0:8], b=out[:, :, 8:11], g=out[:, :, 11:16], d=out[:, :, 16:24])
+
+    def device_bytes(self):
+        return int(lib().mpc_batch_device_bytes(self._h))
 
     def last_phase0_ms(self):
         return float(lib().mpc_batch_last_phase0_ms(self._h))

@@ -93,10 +93,10 @@ template <> __device__ __forceinline__ XBlock make_policy<XBlock>(int t) {
     return XBlock(xb_lds, t);
 }
 
-// Optional direct batch I/O of k_wave in the C-ABI's AoS layouts (device pointers, any may be
-// null): inputs are then read straight from the caller's arrays (lane k reads yref[i][k][0..4],
-// coalesced) instead of from packed workspace rows, and u0 / status / qp_iter are written
-// straight back — no k_pack / k_unpack launches on the wave path.
+// Batch I/O of k_wave in the C-ABI's AoS layouts (device pointers; x0, yref, yref_e and u0 are
+// required, status / qp_iter may be null): inputs are read straight from the caller's arrays
+// (the lane of stage k reads yref[i][k][0..4], coalesced) and u0 / status / qp_iter are written
+// straight back — a wave-model solve is one launch, no pack / unpack, no workspace in HBM.
 struct WaveIO {
     const double* x0;      // [B][3]
     const double* yref;    // [B][N][5]
@@ -117,9 +117,6 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     const bool inst = i < (size_t)B;
     const size_t ic = inst ? i : (size_t)B - 1;
     const int kcl = k <= N ? k : N;
-    double* col = reinterpret_cast<double*>(m.slab + (ic >> 6) * m.wave_bytes) + (ic & 63);
-    double* sk = col + ((size_t)(kcl * MPC_RPS) << 6);
-    double* sN = col + ((size_t)(N * MPC_RPS) << 6);
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     X xpol = make_policy<X>(l);
     // product cache of the scans (rti_wave.hpp build_products): [level][pair][lane] double2
@@ -131,17 +128,12 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     for (int q = 0; q < 3; ++q) xi[q] = on ? ck[C_X + q] : 0.0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) ui[q] = (on && k < N) ? ck[C_U + q] : 0.0;
-    if (io.yref) {
+    {
         const double* yr = k < N ? io.yref + ((size_t)ic * N + kcl) * 5 : io.yref_e + (size_t)ic * 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? io.x0[3 * ic + q] : 0.0;
 #pragma unroll
         for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? yr[q] : 0.0;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) x0b[q] = (on && k == 0) ? sN[(R_X0 + q) << 6] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) w.yref[q] = (on && (k < N || q < 3)) ? sk[(R_YREF + q) << 6] : 0.0;
     }
     const double u_prev0 = ui[0], u_prev1 = ui[1];
     typename Wave<X, SCAN>::State s;
@@ -174,7 +166,8 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
             m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag; m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
             if (io.qp_iter) io.qp_iter[i] = s.kk;
-            if (io.u0) { io.u0[2 * i] = ok ? ui[0] : u_prev0; io.u0[2 * i + 1] = ok ? ui[1] : u_prev1; }
+            // on a QP failure the previous u_0 stays in force
+            io.u0[2 * i] = ok ? ui[0] : u_prev0; io.u0[2 * i + 1] = ok ? ui[1] : u_prev1;
         }
         if (ok) {
 #pragma unroll
@@ -185,19 +178,16 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
                 for (int q = 0; q < 3; ++q) ck[C_PI + q] = w.pi[q];
             }
         }
-        if (k == 0) {   // on a QP failure the previous u_0 stays in force
-            sN[(R_U0 + 0) << 6] = ok ? ui[0] : u_prev0;
-            sN[(R_U0 + 1) << 6] = ok ? ui[1] : u_prev1;
-        }
         return;
     }
     // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update;
     //      the whole loop runs inside the kernel, one OCP per group, no host round trip ----
+    double* lk = m.lam + ((size_t)ic * (N + 1) + kcl) * 8;   // this lane's bound multipliers
     double pin[3], lamn[8], res[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 3; ++q) pin[q] = (on && k < N) ? ck[C_PI + q] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? ck[C_LAM + q] : 0.0;
+    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? lk[q] : 0.0;
     bool running = inst;
     int sqp_it = 0, qp_it = 0, diag = 0;
     status = 2;   // MAXITER unless a residual check passes
@@ -248,10 +238,9 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
-        sN[(R_U0 + 0) << 6] = ui[0]; sN[(R_U0 + 1) << 6] = ui[1];
         if (io.status) io.status[i] = status;
         if (io.qp_iter) io.qp_iter[i] = qp_it;
-        if (io.u0) { io.u0[2 * i] = ui[0]; io.u0[2 * i + 1] = ui[1]; }
+        io.u0[2 * i] = ui[0]; io.u0[2 * i + 1] = ui[1];
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) ck[C_X + q] = xi[q];
@@ -260,7 +249,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 #pragma unroll
         for (int q = 0; q < 3; ++q) ck[C_PI + q] = pin[q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ck[C_LAM + q] = lamn[q];
+        for (int q = 0; q < 8; ++q) lk[q] = lamn[q];
     }
 }
 
@@ -397,65 +386,68 @@ __global__ void k_cap_unpack(double* __restrict__ dst, int nst, int ncomp, int k
     const int st = (int)(r / ncomp), q = (int)(r - (size_t)st * ncomp);
     dst[idx] = m.cap[(i * (N + 1) + kfirst + st) * MPC_CAP + slot + q];
 }
-// Capsule <-> the workspace rows R_X, R_U, R_PI, R_LAM of the lane-per-OCP kernels (only when a
-// handle that owns a capsule is driven through MPC_MODEL_LANE).  One thread per (instance, stage).
+// Capsule (and, on full-SQP handles, the bound multipliers) <-> the workspace rows R_X, R_U, R_PI,
+// R_LAM of the lane-per-OCP kernels: only when a handle is driven through MPC_MODEL_LANE.
+// One thread per (instance, stage).
 __global__ void k_cap_slab(Mem m, int N, int B, int to_slab) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * (N + 1)) return;
     const size_t i = idx / (N + 1);
     const int k = (int)(idx - i * (N + 1));
     double* cl = m.cap + idx * MPC_CAP;
+    double* ll = m.lam ? m.lam + idx * 8 : nullptr;
     double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63) + ((size_t)(k * MPC_RPS) << 6);
     if (to_slab) {
         for (int r = 0; r < 8; ++r) blk[(size_t)r << 6] = cl[r];
-        for (int r = 0; r < 8; ++r) blk[(size_t)(R_LAM + r) << 6] = cl[C_LAM + r];
+        for (int r = 0; r < 8; ++r) blk[(size_t)(R_LAM + r) << 6] = ll ? ll[r] : 0.0;
     } else {
         for (int r = 0; r < 8; ++r) cl[r] = blk[(size_t)r << 6];
-        for (int r = 0; r < 8; ++r) cl[C_LAM + r] = blk[(size_t)(R_LAM + r) << 6];
+        if (ll) for (int r = 0; r < 8; ++r) ll[r] = blk[(size_t)(R_LAM + r) << 6];
     }
 }
 
-// H14: zero x, u, pi of the selected capsules (mobile_robot_acados_reset, :830-869).
+// H14: zero x, u, pi (and the bound multipliers) of the selected capsules
+// (mobile_robot_acados_reset, :830-869).  One thread per (instance, stage).
 __global__ void k_reset(Mem m, int N, const unsigned char* mask, int cap) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)cap) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)cap * (N + 1)) return;
+    const size_t i = idx / (N + 1);
     if (mask && !mask[i]) return;
-    double* blk = reinterpret_cast<double*>(m.slab + (i >> 6) * m.wave_bytes) + (i & 63);
-    if (m.cap)
-        for (int k = 0; k <= N; ++k)
-            for (int r = 0; r < MPC_CAP; ++r) m.cap[(i * (N + 1) + k) * MPC_CAP + r] = 0.0;
-    for (int k = 0; k <= N; ++k)
-    {
-        for (int r = 0; r < R_YREF; ++r)  // rows R_X, R_U, R_PI are the first 8 of a stage
-            blk[(size_t)(k * MPC_RPS + r) << 6] = 0.0;
-        for (int r = R_LAM; r < R_LAM + 8; ++r)  // bound multipliers (read by the full-SQP residual check)
-            blk[(size_t)(k * MPC_RPS + r) << 6] = 0.0;
+    double* cl = m.cap + idx * MPC_CAP;
+#pragma unroll
+    for (int r = 0; r < MPC_CAP; ++r) cl[r] = 0.0;
+    if (m.lam) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m.lam[idx * 8 + r] = 0.0;
     }
 }
 
-// Shifted warm start on the capsule lines cap[instance][stage][MPC_CAP]: one workgroup per
-// instance; every thread reads its elements of line k+1 before anyone writes line k.
+// Shifted warm start on the capsule lines cap[instance][stage][MPC_CAP] (and the multiplier
+// lines): one workgroup per instance; every thread reads its elements of line k+1 before anyone
+// writes line k.  `lines` = cap (width MPC_CAP, x carried into line N-1) or lam (everything of
+// line N-1 kept).
 #define MPC_SHIFT_THREADS 256
-#define MPC_SHIFT_PER_THREAD (((MPC_MAX_N + 1) * MPC_CAP + MPC_SHIFT_THREADS - 1) / MPC_SHIFT_THREADS)
-__global__ __launch_bounds__(MPC_SHIFT_THREADS) void k_shift(Mem m, int N, const unsigned char* mask, int n) {
+#define MPC_SHIFT_PER_THREAD (((MPC_MAX_N + 1) * 8 + MPC_SHIFT_THREADS - 1) / MPC_SHIFT_THREADS)
+static_assert(MPC_CAP == 8, "k_shift assumes 8 doubles per capsule line");
+__global__ __launch_bounds__(MPC_SHIFT_THREADS) void k_shift(double* lines, int N, const unsigned char* mask, int n, int x_cols) {
     const size_t i = blockIdx.x;
     if (i >= (size_t)n) return;
     if (mask && !mask[i]) return;   // uniform per workgroup
-    double* line = m.cap + i * (size_t)(N + 1) * MPC_CAP;
-    const int tot = N * MPC_CAP;    // destination elements: lines 0..N-1
+    double* line = lines + i * (size_t)(N + 1) * 8;
+    const int tot = N * 8;    // destination elements: lines 0..N-1
     double v[MPC_SHIFT_PER_THREAD];
 #pragma unroll
     for (int q = 0; q < MPC_SHIFT_PER_THREAD; ++q) {
         const int e = q * MPC_SHIFT_THREADS + threadIdx.x;
         // line N only carries x_N: the controls and multipliers of the last interval stay
-        const bool take = e < tot && (e < (N - 1) * MPC_CAP || (e % MPC_CAP) < C_U);
-        v[q] = take ? line[e + MPC_CAP] : 0.0;
+        const bool take = e < tot && (e < (N - 1) * 8 || (e % 8) < x_cols);
+        v[q] = take ? line[e + 8] : 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < MPC_SHIFT_PER_THREAD; ++q) {
         const int e = q * MPC_SHIFT_THREADS + threadIdx.x;
-        const bool take = e < tot && (e < (N - 1) * MPC_CAP || (e % MPC_CAP) < C_U);
+        const bool take = e < tot && (e < (N - 1) * 8 || (e % 8) < x_cols);
         if (take) line[e] = v[q];
     }
 }
@@ -485,15 +477,57 @@ __global__ void k_sim_step(Consts c, double* x, const double* u, int B) {
     x[3 * i] = x0; x[3 * i + 1] = x1; x[3 * i + 2] = psi;
 }
 
+// Development / test hook (mpc_batch_debug_linearize): what the preparation phase hands to the QP
+// at the capsules' current iterate, one thread per (instance, stage), written AoS as
+// out[i][k][24] = a, b, B00, B10, B20, B01, B11, B21 (the non-trivial entries of A_k, B_k; H5/H7),
+// b_k = phi(x_k, u_k) - x_{k+1} (3), the LINEAR_LS gradient in [v, delta, x, y, psi] order (5; H8),
+// the BGH bound residuals lb - z (4) and z - ub (4) on (v, delta, x, y) (H9).  Entries a stage
+// does not have (stage N: dynamics, controls, bounds; stage 0: state gradient and state bounds,
+// x0 being eliminated) are 0.  Uses the same Algebra::linearize_math as the solve kernels.
+__global__ void k_debug_lin(Consts c, Mem m, const double* __restrict__ yref, const double* __restrict__ yref_e, int B,
+                            double* __restrict__ out) {
+    const int N = c.N;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * (N + 1)) return;
+    const size_t i = idx / (N + 1);
+    const int k = (int)(idx - i * (N + 1));
+    const double* cl = m.cap + idx * MPC_CAP;
+    double* o = out + idx * 24;
+    for (int q = 0; q < 24; ++q) o[q] = 0.0;
+    const double x0 = cl[C_X], x1 = cl[C_X + 1], psi = cl[C_X + 2];
+    if (k < N) {
+        const double v = cl[C_U], dl = cl[C_U + 1];
+        Algebra alg(c);
+        Algebra::AB8 ab;
+        double cv[3], xn[3];
+        alg.linearize_math(x0, x1, psi, v, dl, ab, cv, xn);
+        o[0] = ab.a; o[1] = ab.b; o[2] = ab.B00; o[3] = ab.B10; o[4] = ab.B20; o[5] = ab.B01; o[6] = ab.B11; o[7] = ab.B21;
+        const double* cn = cl + MPC_CAP;
+        for (int q = 0; q < 3; ++q) o[8 + q] = xn[q] - cn[C_X + q];
+        const double* yr = yref + (i * N + k) * 5;
+        const double z[5] = {v, dl, x0, x1, psi};
+        o[11] = c.wg[0] * (z[0] - yr[3]);
+        o[12] = c.wg[1] * (z[1] - yr[4]);
+        for (int q = 0; q < 3; ++q) o[13 + q] = k > 0 ? c.wg[2 + q] * (z[2 + q] - yr[q]) : 0.0;
+        const int nb = k == 0 ? 2 : 4;
+        for (int j = 0; j < nb; ++j) { o[16 + j] = c.lb[j] - z[j]; o[20 + j] = z[j] - c.ub[j]; }
+    } else {
+        const double z[3] = {x0, x1, psi};
+        for (int q = 0; q < 3; ++q) o[13 + q] = c.we[q] * (z[q] - yref_e[3 * i + q]);
+    }
+}
+
 // ---- closed loop on the device: H2 + the packing half of H1 + H16 --------
 // Per-vehicle tracker state; one shared path table (state_refs [M][3], input_refs [Mi][2]).
 struct Track {
     const double* sref;   // [M][3]
     const double* iref;   // [Mi][2]
     int M, Mi;
-    double* x;            // [S][3] current state (Optimizer::x_current)
+    double* x;            // [S][3] current state (Optimizer::x_current) = the x0 of the next solve
     double* u;            // [S][2] command in force (Optimizer::u_current)
     int* idx;             // [S][4] target_waypoint_index, last_waypoint_index, closest_waypoint_index, count
+    double* yref;         // [S][N][5] references of the tick, the C-ABI's AoS layout
+    double* yref_e;       // [S][3]
     double density;       // 1 / T / v_ref                     (src/optimizer.cpp:128)
     int limit;            // floor(3.95 / (v_ref * T))         (src/optimizer.cpp:387-391)
     int lookahead;        // 1
@@ -515,15 +549,11 @@ __device__ __forceinline__ int closest_waypoint(const Track& tr, double cx, doub
     return closest;
 }
 
-// One thread per vehicle: Optimizer::find_next_waypoint (src/optimizer.cpp:384-431) and the
-// reference packing of Optimizer::update_and_solve (:240-281), written straight into the
-// workspace rows the solve reads (R_YREF, R_YREFE, R_X0) — no AoS staging, no host round trip.
-__global__ __launch_bounds__(MPC_WAVE) void k_track_select(Consts c, Mem m, Track tr, int B) {
-    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
-    const unsigned l = threadIdx.x;
-    const size_t i = wbase + l;
+// One thread per vehicle: Optimizer::find_next_waypoint (src/optimizer.cpp:384-431).
+__global__ __launch_bounds__(MPC_WAVE) void k_track_select(Track tr, int B) {
+    const size_t i = (size_t)blockIdx.x * MPC_WAVE + threadIdx.x;
     if (i >= (size_t)B) return;
-    const double cx = tr.x[3 * i], cy = tr.x[3 * i + 1], cpsi = tr.x[3 * i + 2];
+    const double cx = tr.x[3 * i], cy = tr.x[3 * i + 1];
     int target = tr.idx[4 * i], last = tr.idx[4 * i + 1], count = tr.idx[4 * i + 3];
     int closest = closest_waypoint(tr, cx, cy, -1, -1, last, target);
     if (closest < 0) closest = last < tr.M - 1 ? last : tr.M - 1;   // empty window (the reference would index -1)
@@ -539,31 +569,37 @@ __global__ __launch_bounds__(MPC_WAVE) void k_track_select(Consts c, Mem m, Trac
     else { target = target + 1; count = count + 1; }
     if (target > tr.M - 1) target = tr.M - 1;
     tr.idx[4 * i] = target; tr.idx[4 * i + 1] = target; tr.idx[4 * i + 2] = closest; tr.idx[4 * i + 3] = count;
-    Lane lane(c, m, wbase, l);
-    const int N = c.N;
-    for (int j = 0; j < N; ++j) {
+}
+// The reference packing of Optimizer::update_and_solve (:240-281), one thread per (vehicle,
+// stage), written in the C-ABI's AoS layout that the solve reads (coalesced across the stages of
+// a vehicle); stage N writes the terminal reference.
+__global__ void k_track_pack(Track tr, int N, int B) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * (N + 1)) return;
+    const size_t i = idx / (N + 1);
+    const int j = (int)(idx - i * (N + 1));
+    const int target = tr.idx[4 * i];
+    if (j < N) {
         const bool past = target + j >= tr.M;
         const int r = past ? tr.M - 1 : target + j;
-        lane.st(R_YREF, j, 0, tr.sref[3 * r]); lane.st(R_YREF, j, 1, tr.sref[3 * r + 1]); lane.st(R_YREF, j, 2, tr.sref[3 * r + 2]);
-        lane.st(R_YREF, j, 3, (past || r >= tr.Mi) ? 0.0 : tr.iref[2 * r]);
-        lane.st(R_YREF, j, 4, 0.0);   // "set steer rate to 0" (:271)
+        double* y = tr.yref + (i * N + j) * 5;
+        y[0] = tr.sref[3 * r]; y[1] = tr.sref[3 * r + 1]; y[2] = tr.sref[3 * r + 2];
+        y[3] = (past || r >= tr.Mi) ? 0.0 : tr.iref[2 * r];
+        y[4] = 0.0;   // "set steer rate to 0" (:271)
+    } else {
+        double* y = tr.yref_e + 3 * i;   // terminal reference = the FIRST waypoint of the window (:244-251)
+        y[0] = tr.sref[3 * target]; y[1] = tr.sref[3 * target + 1]; y[2] = tr.sref[3 * target + 2];
     }
-    lane.st(R_YREFE, N, 0, tr.sref[3 * target]); lane.st(R_YREFE, N, 1, tr.sref[3 * target + 1]);
-    lane.st(R_YREFE, N, 2, tr.sref[3 * target + 2]);
-    lane.st(R_X0, N, 0, cx); lane.st(R_X0, N, 1, cy); lane.st(R_X0, N, 2, cpsi);
 }
 
 // After the solve: adopt u0 unless the solver failed (src/optimizer.cpp:290-296), then
 // Optimizer::integrate_next_states (:321-341).
-__global__ __launch_bounds__(MPC_WAVE) void k_track_advance(Consts c, Mem m, Track tr, int B) {
-    const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
-    const unsigned l = threadIdx.x;
-    const size_t i = wbase + l;
+__global__ __launch_bounds__(MPC_WAVE) void k_track_advance(Consts c, Mem m, Track tr, const double* u0, int B) {
+    const size_t i = (size_t)blockIdx.x * MPC_WAVE + threadIdx.x;
     if (i >= (size_t)B) return;
-    Lane lane(c, m, wbase, l);
     double v = tr.u[2 * i], dl = tr.u[2 * i + 1];
     if (m.STATUS[i] == 0) {
-        v = lane.ld(R_U0, c.N, 0); dl = lane.ld(R_U0, c.N, 1);
+        v = u0[2 * i]; dl = u0[2 * i + 1];
         tr.u[2 * i] = v; tr.u[2 * i + 1] = dl;
     }
     double x0 = tr.x[3 * i], x1 = tr.x[3 * i + 1], psi = tr.x[3 * i + 2];
@@ -581,26 +617,34 @@ struct Shard {
     size_t S = 0;      // padded stride
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_ph[MPC_MAX_PHASES + 1] = {};  // boundaries of the k_phase launches of the last solve
+    hipEvent_t ev_ph[2] = {};   // around the dominant solve kernel of the last solve
     int n_ph = 0;
-    int sqp_rounds = 0;  // QP rounds of the last full-SQP solve
-    char* slab = nullptr;    // primary workspace: capsules (home), inputs, phase 0
-    char* slab2 = nullptr;   // secondary workspace for compacted stragglers (lazily sized)
-    double* capbuf = nullptr;  // AoS capsule of the wave model (N <= 63), see Mem::cap
+    int sqp_rounds = 0;  // QP rounds of the last full-SQP solve (lane model)
+    // allocated by mpc_batch_create: the capsules, the small per-instance arrays, u0
+    double* capbuf = nullptr;  // Mem::cap
+    double* lambuf = nullptr;  // Mem::lam (full-SQP handles only)
     int* islab = nullptr;
+    double* d_u0 = nullptr;    // [S][2] u_0 of the last solve when the caller passes none
+    // lane model only, allocated on its first use (ensure_lane)
+    char* slab = nullptr;    // workspace: inputs, iterate rows, IPM workspace
+    char* slab2 = nullptr;   // secondary workspace for compacted stragglers (first large lane solve)
     int* phase_ints = nullptr;  // [MPC_MAX_PHASES] live counts, then [S] flags
     Mem mem, mem2;
-    // AoS staging for the host-pointer entry points
+    // AoS staging for the host-pointer entry points, allocated on first use (ensure_staging):
+    // device buffers + pinned host mirrors (so that the copies of several shards overlap)
     double *s_x0 = nullptr, *s_yref = nullptr, *s_yrefe = nullptr, *s_u0 = nullptr;
     double *s_xt = nullptr, *s_ut = nullptr, *s_pi = nullptr;
     unsigned char* s_mask = nullptr;
+    bool staged = false, staged_traj = false;
     // pinned, device-visible host staging for small batches (zero-copy latency path)
     double* z_in = nullptr;   // x0 [Z][3] | yref [Z][N][5] | yref_e [Z][3]
     double* z_out = nullptr;  // u0 [Z][2] | status [Z] (int) | qp_iter [Z] (int)
     // closed-loop tracker (mpc_batch_track_*): path table and per-vehicle state
-    double *t_sref = nullptr, *t_iref = nullptr, *t_x = nullptr, *t_u = nullptr;
+    double *t_sref = nullptr, *t_iref = nullptr, *t_x = nullptr, *t_u = nullptr, *t_yref = nullptr, *t_yrefe = nullptr;
     int* t_idx = nullptr;
     int t_M = 0, t_Mi = 0;
+    int t_n = 0;               // vehicles initialised by the last mpc_batch_track_init
+    size_t dev_bytes = 0;      // device memory this shard holds
 };
 
 struct mpc_batch {
@@ -634,17 +678,25 @@ struct DeviceGuard {
         }                                                                                \
     } while (0)
 
+// hipMalloc + accounting of the shard's device footprint
+#define DEVALLOC(h, s, ptr, nbytes)                                                      \
+    do {                                                                                 \
+        HIPCHK(h, hipMalloc((void**)&(ptr), (nbytes)));                                  \
+        (s).dev_bytes += (size_t)(nbytes);                                               \
+    } while (0)
+
 static void free_shard(Shard& s) {
     if (s.device < 0) return;
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
-    (void)hipFree(s.capbuf);
+    (void)hipFree(s.capbuf); (void)hipFree(s.lambuf); (void)hipFree(s.d_u0);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
     if (s.z_in) (void)hipHostFree(s.z_in);
     if (s.z_out) (void)hipHostFree(s.z_out);
     (void)hipFree(s.t_sref); (void)hipFree(s.t_iref); (void)hipFree(s.t_x); (void)hipFree(s.t_u); (void)hipFree(s.t_idx);
+    (void)hipFree(s.t_yref); (void)hipFree(s.t_yrefe);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     for (hipEvent_t e : s.ev_ph) if (e) (void)hipEventDestroy(e);
@@ -652,61 +704,61 @@ static void free_shard(Shard& s) {
     s = Shard();
 }
 
-static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
-// iterate rows (x, u, pi) live in the AoS capsule when the shard has one, else in the slab
-static void pack_iter(const Mem& m, int N, hipStream_t st, const double* src, int nst, int ncomp, int row, int n) {
-    if (m.cap) {
-        const size_t tot = (size_t)n * nst * ncomp;
-        hipLaunchKernelGGL(k_cap_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, nst, ncomp, 0, row, m, N, n);
-    } else {
-        hipLaunchKernelGGL(k_pack, tgrid(nst * ncomp, n), dim3(32, 8), 0, st, src, nst, ncomp, 0, row, m, n);
+// Every shard, even on an error: the work already enqueued on the other shards is waited for
+// before an entry point returns, so the caller's buffers are never written after the return.
+static void sync_all(mpc_batch* h) {
+    for (Shard& s : h->shards) {
+        if (s.device < 0 || !s.stream) continue;
+        (void)hipSetDevice(s.device);
+        (void)hipStreamSynchronize(s.stream);
     }
 }
-static void unpack_iter(const Mem& m, int N, hipStream_t st, double* dst, int nst, int ncomp, int row, int n) {
-    if (m.cap) {
-        const size_t tot = (size_t)n * nst * ncomp;
-        hipLaunchKernelGGL(k_cap_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dst, nst, ncomp, 0, row, m, N, n);
-    } else {
-        hipLaunchKernelGGL(k_unpack, tgrid(nst * ncomp, n), dim3(32, 8), 0, st, dst, nst, ncomp, 0, row, m, n);
-    }
-}
-struct WaveIO;
-static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO* io = nullptr);
-static int pick_model(const mpc_batch* h);
 
-// Enqueue the device work of one solve on shard s for its first `n` instances; all pointers
-// are device pointers in the C-ABI's AoS layouts (any of the optional ones may be null).
-static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, const double* d_yref,
-                         const double* d_yrefe, double* d_u0, double* d_xt, double* d_ut, int* d_status,
-                         int* d_iter, hipStream_t st) {
+// Lane model: its workspace slab is allocated on the first solve that uses it, so a handle that
+// only ever runs the wave model holds the capsules and little else.
+static int ensure_lane(mpc_batch* h, Shard& s, hipStream_t st) {
+    if (s.slab) return 0;
     const int N = h->spec.N;
-    const dim3 tb(32, 8);
-    Mem& m = s.mem;
-    const bool wave = pick_model(h) != MPC_MODEL_LANE;
-    if (!wave) {
-        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_x0, 1, 3, N, (int)R_X0, m, n);
-        hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
-        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
+    const size_t capa = (size_t)(s.cap > 0 ? s.cap : 1);
+    const size_t nbytes = slab_bytes_for(N, capa);
+    DEVALLOC(h, s, s.slab, nbytes);
+    HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, st));
+    DEVALLOC(h, s, s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int));
+    HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), st));
+    s.mem.slab = s.slab;
+    return 0;
+}
+// Device staging of the host-pointer entry points, allocated on their first use.
+static int ensure_staging(mpc_batch* h, Shard& s, bool traj) {
+    const int N = h->spec.N;
+    const size_t capa = (size_t)(s.cap > 0 ? s.cap : 1);
+    if (!s.staged) {
+        DEVALLOC(h, s, s.s_x0, sizeof(double) * 3 * capa);
+        DEVALLOC(h, s, s.s_yref, sizeof(double) * 5 * N * capa);
+        DEVALLOC(h, s, s.s_yrefe, sizeof(double) * 3 * capa);
+        DEVALLOC(h, s, s.s_u0, sizeof(double) * 2 * capa);
+        DEVALLOC(h, s, s.s_mask, capa);
+        s.staged = true;
     }
-    if (d_xt) pack_iter(m, N, st, d_xt, N + 1, 3, (int)R_X, n);
-    if (d_ut) pack_iter(m, N, st, d_ut, N, 2, (int)R_U, n);
-    WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
-    int rc = enqueue_core(h, s, n, st, wave ? &io : nullptr);
-    if (rc != 0) return rc;
-    if (wave) {   // inputs and u0 / status / qp_iter went through k_wave directly
-        d_u0 = nullptr; d_status = nullptr; d_iter = nullptr;
+    if (traj && !s.staged_traj) {
+        DEVALLOC(h, s, s.s_xt, sizeof(double) * 3 * (N + 1) * capa);
+        DEVALLOC(h, s, s.s_ut, sizeof(double) * 2 * N * capa);
+        DEVALLOC(h, s, s.s_pi, sizeof(double) * 3 * N * capa);
+        s.staged_traj = true;
     }
-    if (d_u0) hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
-    if (d_xt) unpack_iter(m, N, st, d_xt, N + 1, 3, (int)R_X, n);
-    if (d_ut) unpack_iter(m, N, st, d_ut, N, 2, (int)R_U, n);
-    if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
-    if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// The solve proper on inputs already in the workspace rows (R_X0, R_YREF, R_YREFE; iterate in
-// R_X, R_U): one RTI step, or the full SQP loop.
+static dim3 tgrid(int R, int B) { return dim3((R + 31) / 32, (B + 63) / 64); }
+static void pack_iter(const Mem& m, int N, hipStream_t st, const double* src, int nst, int ncomp, int slot, int n) {
+    const size_t tot = (size_t)n * nst * ncomp;
+    hipLaunchKernelGGL(k_cap_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, nst, ncomp, 0, slot, m, N, n);
+}
+static void unpack_iter(const Mem& m, int N, hipStream_t st, double* dst, int nst, int ncomp, int slot, int n) {
+    const size_t tot = (size_t)n * nst * ncomp;
+    hipLaunchKernelGGL(k_cap_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dst, nst, ncomp, 0, slot, m, N, n);
+}
+
 // MPC_MODEL_LANE or a wave model, after AUTO / environment / applicability are resolved
 static int pick_model(const mpc_batch* h) {
     static const char* model_env = getenv("MPC_MODEL");
@@ -717,55 +769,29 @@ static int pick_model(const mpc_batch* h) {
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
     }
     if (model == MPC_MODEL_AUTO) model = MPC_MODEL_WAVE;
-    if (h->spec.N + 1 > MPC_XB_LANES) model = MPC_MODEL_LANE;
     return model;
 }
 
-static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO* io) {
+// The lane-model solve on inputs already packed into the workspace rows (R_X0, R_YREF, R_YREFE):
+// capsule -> rows, one RTI step (phased, with straggler compaction) or the host-driven SQP loop,
+// rows -> capsule.
+static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     const int N = h->spec.N;
     Mem& m = s.mem;
     const bool sqp = h->spec.sqp_max_iter > 1;
     const int iters = sqp ? h->spec.sqp_max_iter : 1;
     const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
     s.sqp_rounds = 0;
-    const int model = pick_model(h);
-    const bool use_wave = model != MPC_MODEL_LANE;
-    if (use_wave) {
-        // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
-        // the parallel scans (development / cross-check; RTI only)
-        const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
-        const int mi = h->spec.sqp_max_iter;
-        WaveIO wio;
-        if (io) wio = *io; else memset(&wio, 0, sizeof(wio));
-        HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-#define MPC_LAUNCH_WAVE(X_)                                                                                               \
-        do {                                                                                                              \
-            const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                    \
-            if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);             \
-            else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);      \
-            else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);                \
-        } while (0)
-        if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
-        else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
-        else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
-        else MPC_LAUNCH_WAVE(XBlock);
-#undef MPC_LAUNCH_WAVE
-        HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
-        s.n_ph = 1;
-        HIPCHK(h, hipGetLastError());
-        return 0;
-    }
     if (n > MPC_SINGLE_PHASE_MAX && !s.slab2) {
-        // second workspace for the compacted stragglers of the phased solve, allocated on the
-        // first large lane-model solve (handles that only ever run the wave model never pay for it)
+        // second workspace for the compacted stragglers of the phased solve
         const size_t nbytes = slab_bytes_for(N, (size_t)(s.cap > 0 ? s.cap : 1));
-        HIPCHK(h, hipMalloc(&s.slab2, nbytes));
+        DEVALLOC(h, s, s.slab2, nbytes);
         HIPCHK(h, hipMemsetAsync(s.slab2, 0, nbytes, st));
-        s.mem2 = make_mem(s.slab2, s.islab, (size_t)(s.cap > 0 ? s.cap : 1), N);
-        s.mem2.cap = s.capbuf;
+        s.mem2 = s.mem;
+        s.mem2.slab = s.slab2;
     }
     const unsigned cgrid = (unsigned)(((size_t)n * (N + 1) + 255) / 256);
-    if (m.cap) hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
+    hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
     for (int it = 0; it < iters; ++it) {
         if (sqp) {
             // head of an SQP iteration; the host reads the number of instances still iterating
@@ -789,10 +815,9 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
             // phases 0..P-1; a wave hands over when fewer than MINACT of its lanes still iterate.
             // Measured on MI355X (65536 x N=50): P=2, MINACT=8 is the optimum (20.4 ms/tick vs 25.0
             // single-phase; more phases or an earlier hand-over cost more in compaction traffic
-            // than they save).  MPC_PHASES / MPC_MIN_ACTIVE override for experiments.
-            static const int P0 = getenv("MPC_PHASES") ? atoi(getenv("MPC_PHASES")) : 2;
-            const int P = P0 < 1 ? 1 : (P0 > MPC_MAX_PHASES - 1 ? MPC_MAX_PHASES - 1 : P0);
-            static const int MINACT = getenv("MPC_MIN_ACTIVE") ? atoi(getenv("MPC_MIN_ACTIVE")) : MPC_WAVE / 8;
+            // than they save).
+            const int P = 2;
+            const int MINACT = MPC_WAVE / 8;
             int* counts = s.phase_ints;
             int* flags = s.phase_ints + MPC_MAX_PHASES;
             HIPCHK(h, hipMemsetAsync(counts, 0, MPC_MAX_PHASES * sizeof(int), st));
@@ -811,19 +836,84 @@ static int enqueue_core(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
             s.n_ph = 1;
         }
     }
-    if (m.cap) hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 0);   // workspace rows -> capsule
+    hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 0);   // workspace rows -> capsule
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// The wave-model solve: one launch that reads the C-ABI's arrays and the capsules and writes
+// them back.  io.x0 / yref / yref_e / u0 must be set.
+static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
+    const int N = h->spec.N;
+    const Mem& m = s.mem;
+    const bool sqp = h->spec.sqp_max_iter > 1;
+    // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
+    // the parallel scans (development / cross-check; RTI only)
+    const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
+    const int mi = h->spec.sqp_max_iter;
+    HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+#define MPC_LAUNCH_WAVE(X_)                                                                                               \
+    do {                                                                                                                  \
+        const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                        \
+        if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);                 \
+        else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);          \
+        else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);                    \
+    } while (0)
+    if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
+    else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
+    else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
+    else MPC_LAUNCH_WAVE(XBlock);
+#undef MPC_LAUNCH_WAVE
+    HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
+    s.n_ph = 1;
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// Enqueue the device work of one solve on shard s for its first `n` instances; all pointers are
+// device (or device-visible) pointers in the C-ABI's AoS layouts; d_u0 / d_xt / d_ut / d_status /
+// d_iter may be null.
+static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, const double* d_yref,
+                         const double* d_yrefe, double* d_u0, double* d_xt, double* d_ut, int* d_status,
+                         int* d_iter, hipStream_t st) {
+    const int N = h->spec.N;
+    const dim3 tb(32, 8);
+    Mem& m = s.mem;
+    const int model = pick_model(h);
+    if (!d_u0) d_u0 = s.d_u0;
+    if (d_xt) pack_iter(m, N, st, d_xt, N + 1, 3, (int)C_X, n);
+    if (d_ut) pack_iter(m, N, st, d_ut, N, 2, (int)C_U, n);
+    if (model != MPC_MODEL_LANE) {
+        const WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
+        int rc = enqueue_wave(h, s, n, st, io, model);
+        if (rc != 0) return rc;
+    } else {
+        int rc = ensure_lane(h, s, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_x0, 1, 3, N, (int)R_X0, m, n);
+        hipLaunchKernelGGL(k_pack, tgrid(5 * N, n), tb, 0, st, d_yref, N, 5, 0, (int)R_YREF, m, n);
+        hipLaunchKernelGGL(k_pack, tgrid(3, n), tb, 0, st, d_yrefe, 1, 3, N, (int)R_YREFE, m, n);
+        rc = enqueue_lane(h, s, n, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
+        if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+        if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+    }
+    if (d_xt) unpack_iter(m, N, st, d_xt, N + 1, 3, (int)C_X, n);
+    if (d_ut) unpack_iter(m, N, st, d_ut, N, 2, (int)C_U, n);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
 extern "C" {
 
-const char* mpc_batch_version(void) { return "mpc_amd 0.2 (gfx950 FP64: wave-per-OCP parallel-in-time + lane-per-OCP)"; }
+const char* mpc_batch_version(void) { return "mpc_amd 0.3 (gfx950 FP64: wave-per-OCP parallel-in-time + lane-per-OCP)"; }
 
 int mpc_spec_variant(const char* name, mpc_ocp_spec_t* s) {
     if (!name || !s) return -1;
     struct Row { const char* n; int N; double Ts, W[5], We[3], lbu[2], ubu[2], lbx[2], ubx[2]; };
-    // SURVEY.md §2.1 (generated acados_solver_<name>.c of every variant)
+    // SURVEY.md §2.1 (generated acados_solver_<name>.c of every variant); pinned against the
+    // reference's own files by tests/golden/ocp_constants.json (tests/test_variants_golden.py)
     static const Row rows[] = {
         {"mobile_robot", 50, 0.05, {2, 2, 0.5, 1, 0.1}, {2, 2, 0.5}, {-0.25, -0.42}, {0.375, 0.42}, {-2, -2}, {22, 16}},
         {"mobile_robot_18", 40, 0.125, {2, 2, 0.5, 1, 0.1}, {2, 2, 0.5}, {-0.4, -0.42}, {0.4, 0.42}, {-1, -1}, {22, 16}},
@@ -849,7 +939,11 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
                      int n_devices) {
     if (!out) return -1;
     *out = nullptr;
-    if (!spec_valid(spec) || capacity < 1) return -1;
+    if (const char* why = spec_problem(spec)) {
+        fprintf(stderr, "mpc_batch_create: %s\n", why);
+        return -1;
+    }
+    if (capacity < 1) return -1;
     int ndev_avail = 0;
     if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail < 1) return -3;
     std::vector<int> devs;
@@ -886,29 +980,22 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             HIPCHK(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreate(&s.ev0));
             HIPCHK(h, hipEventCreate(&s.ev1));
-            for (int q = 0; q <= MPC_MAX_PHASES; ++q) HIPCHK(h, hipEventCreate(&s.ev_ph[q]));
-            const size_t nbytes = slab_bytes_for(N, (size_t)capa);
-            HIPCHK(h, hipMalloc(&s.slab, nbytes));
-            HIPCHK(h, hipMalloc(&s.islab, islab_ints_for((size_t)capa) * sizeof(int)));
-            HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, s.stream));
+            for (hipEvent_t& e : s.ev_ph) HIPCHK(h, hipEventCreate(&e));
+            DEVALLOC(h, s, s.islab, islab_ints_for((size_t)capa) * sizeof(int));
             HIPCHK(h, hipMemsetAsync(s.islab, 0, islab_ints_for((size_t)capa) * sizeof(int), s.stream));
-            s.mem = make_mem(s.slab, s.islab, (size_t)capa, N);
-            if (N + 1 <= MPC_XB_LANES) {
-                const size_t cb = cap_doubles_for(N, (size_t)capa) * sizeof(double);
-                HIPCHK(h, hipMalloc(&s.capbuf, cb));
-                HIPCHK(h, hipMemsetAsync(s.capbuf, 0, cb, s.stream));
-                s.mem.cap = s.capbuf;
+            s.mem = make_mem(s.islab, (size_t)capa, N);
+            const size_t cb = cap_doubles_for(N, (size_t)capa) * sizeof(double);
+            DEVALLOC(h, s, s.capbuf, cb);
+            HIPCHK(h, hipMemsetAsync(s.capbuf, 0, cb, s.stream));
+            s.mem.cap = s.capbuf;
+            if (spec->sqp_max_iter > 1) {   // the bound multipliers only feed back in full SQP
+                DEVALLOC(h, s, s.lambuf, cb);
+                HIPCHK(h, hipMemsetAsync(s.lambuf, 0, cb, s.stream));
+                s.mem.lam = s.lambuf;
             }
-            HIPCHK(h, hipMalloc(&s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int)));
-            HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), s.stream));
-            HIPCHK(h, hipMalloc(&s.s_x0, sizeof(double) * 3 * capa));
-            HIPCHK(h, hipMalloc(&s.s_yref, sizeof(double) * 5 * N * capa));
-            HIPCHK(h, hipMalloc(&s.s_yrefe, sizeof(double) * 3 * capa));
-            HIPCHK(h, hipMalloc(&s.s_u0, sizeof(double) * 2 * capa));
-            HIPCHK(h, hipMalloc(&s.s_xt, sizeof(double) * 3 * (N + 1) * capa));
-            HIPCHK(h, hipMalloc(&s.s_ut, sizeof(double) * 2 * N * capa));
-            HIPCHK(h, hipMalloc(&s.s_pi, sizeof(double) * 3 * N * capa));
-            HIPCHK(h, hipMalloc(&s.s_mask, capa));
+            DEVALLOC(h, s, s.d_u0, sizeof(double) * 2 * s.S);
+            HIPCHK(h, hipMemsetAsync(s.d_u0, 0, sizeof(double) * 2 * s.S, s.stream));
+            s.mem2 = s.mem;
             {
                 const size_t Z = capa < MPC_ZEROCOPY_MAX ? capa : MPC_ZEROCOPY_MAX;
                 HIPCHK(h, hipHostMalloc((void**)&s.z_in, sizeof(double) * Z * (6 + 5 * (size_t)N), hipHostMallocMapped));
@@ -941,6 +1028,7 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
                            int* d_status, int* d_qp_iter, void* stream) {
     if (!h || B < 1 || B > h->capacity || !d_x0 || !d_yref || !d_yref_e) return -1;
     if (h->shards.size() != 1) { h->err = "mpc_batch_solve_device needs a single-device handle"; return -1; }
+    if ((d_xtraj == nullptr) != (d_utraj == nullptr)) { h->err = "xtraj and utraj must be given together"; return -1; }
     Shard& s = h->shards[0];
     hipStream_t st = stream ? (hipStream_t)stream : s.stream;
     DeviceGuard device_guard;
@@ -972,10 +1060,9 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         double* zu0 = s.z_out;
         int* zst = reinterpret_cast<int*>(zu0 + 2 * (size_t)B);
         int* zit = zst + B;
-        WaveIO io = {zx0, zyr, zye, zu0, zst, zit};
         HIPCHK(h, hipEventRecord(s.ev0, s.stream));
-        int rc = enqueue_core(h, s, B, s.stream, &io);
-        if (rc != 0) return rc;
+        int rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream);
+        if (rc != 0) { sync_all(h); return rc; }
         HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
         if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
@@ -985,32 +1072,41 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) h->last_ms = ms;
         return 0;
     }
-    // enqueue on every shard, then wait for all: shards run concurrently
-    for (Shard& s : h->shards) {
-        const int n = B - s.first < s.cap ? B - s.first : s.cap;
-        if (n <= 0) continue;
-        const size_t o = (size_t)s.first;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipMemcpyAsync(s.s_x0, x0 + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
-        HIPCHK(h, hipMemcpyAsync(s.s_yref, yref + 5 * N * o, sizeof(double) * 5 * N * n, hipMemcpyHostToDevice, s.stream));
-        HIPCHK(h, hipMemcpyAsync(s.s_yrefe, yref_e + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
-        if (xtraj) {
-            HIPCHK(h, hipMemcpyAsync(s.s_xt, xtraj + 3 * (N + 1) * o, sizeof(double) * 3 * (N + 1) * n, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(h, hipMemcpyAsync(s.s_ut, utraj + 2 * N * o, sizeof(double) * 2 * N * n, hipMemcpyHostToDevice, s.stream));
-        }
-        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
-        int rc = enqueue_solve(h, s, n, s.s_x0, s.s_yref, s.s_yrefe, s.s_u0, xtraj ? s.s_xt : nullptr,
+    // enqueue on every shard, then wait for all.  (Copies from pageable host memory are staged by
+    // the runtime and serialise with the host; callers that want the shards' copies to overlap
+    // pass pinned arrays — hipHostMalloc / hipHostRegister — or use one handle per device.)
+    auto body = [&]() -> int {
+        for (Shard& s : h->shards) {
+            const int n = B - s.first < s.cap ? B - s.first : s.cap;
+            if (n <= 0) continue;
+            const size_t o = (size_t)s.first;
+            HIPCHK(h, hipSetDevice(s.device));
+            int rc = ensure_staging(h, s, xtraj != nullptr);
+            if (rc != 0) return rc;
+            HIPCHK(h, hipMemcpyAsync(s.s_x0, x0 + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(h, hipMemcpyAsync(s.s_yref, yref + 5 * N * o, sizeof(double) * 5 * N * n, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(h, hipMemcpyAsync(s.s_yrefe, yref_e + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+            if (xtraj) {
+                HIPCHK(h, hipMemcpyAsync(s.s_xt, xtraj + 3 * (N + 1) * o, sizeof(double) * 3 * (N + 1) * n, hipMemcpyHostToDevice, s.stream));
+                HIPCHK(h, hipMemcpyAsync(s.s_ut, utraj + 2 * N * o, sizeof(double) * 2 * N * n, hipMemcpyHostToDevice, s.stream));
+            }
+            HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+            rc = enqueue_solve(h, s, n, s.s_x0, s.s_yref, s.s_yrefe, s.s_u0, xtraj ? s.s_xt : nullptr,
                                xtraj ? s.s_ut : nullptr, nullptr, nullptr, s.stream);
-        if (rc != 0) return rc;
-        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
-        if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
-        if (xtraj) {
-            HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
-            HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+            if (rc != 0) return rc;
+            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+            if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
+            if (xtraj) {
+                HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
+                HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+            }
+            if (status) HIPCHK(h, hipMemcpyAsync(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
+            if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter + o, s.mem.QPITER, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
         }
-        if (status) HIPCHK(h, hipMemcpyAsync(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
-        if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter + o, s.mem.QPITER, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
-    }
+        return 0;
+    };
+    const int rc = body();
+    if (rc != 0) { sync_all(h); return rc; }
     double worst = 0.0;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
@@ -1024,44 +1120,62 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
     return 0;
 }
 
+// mask [capacity] (host) -> the shard's device copy; returns the device pointer or null for "all"
+static int stage_mask(mpc_batch* h, Shard& s, const unsigned char* mask, const unsigned char** d_mask) {
+    *d_mask = nullptr;
+    if (!mask) return 0;
+    int rc = ensure_staging(h, s, false);
+    if (rc != 0) return rc;
+    HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
+    *d_mask = s.s_mask;
+    return 0;
+}
+
 int mpc_batch_reset(mpc_batch_t* h, const unsigned char* mask) {
     if (!h) return -1;
     const int N = h->spec.N;
     DeviceGuard device_guard;
+    int rc = 0;
     for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        if (mask) HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
-        hipLaunchKernelGGL(k_reset, dim3((s.cap + 255) / 256), dim3(256), 0, s.stream, s.mem, N,
-                           mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
-        HIPCHK(h, hipGetLastError());
+        if (s.cap <= 0 || rc != 0) continue;
+        auto body = [&]() -> int {
+            HIPCHK(h, hipSetDevice(s.device));
+            const unsigned char* dm = nullptr;
+            int r = stage_mask(h, s, mask, &dm);
+            if (r != 0) return r;
+            const size_t tot = (size_t)s.cap * (N + 1);
+            hipLaunchKernelGGL(k_reset, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s.stream, s.mem, N, dm, s.cap);
+            HIPCHK(h, hipGetLastError());
+            return 0;
+        };
+        rc = body();
     }
-    for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
-    }
-    return 0;
+    sync_all(h);
+    return rc;
 }
 
 int mpc_batch_shift(mpc_batch_t* h, const unsigned char* mask) {
     if (!h) return -1;
     const int N = h->spec.N;
     DeviceGuard device_guard;
+    int rc = 0;
     for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        if (mask) HIPCHK(h, hipMemcpyAsync(s.s_mask, mask + s.first, s.cap, hipMemcpyHostToDevice, s.stream));
-        hipLaunchKernelGGL(k_shift, dim3(s.cap), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem, N,
-                           mask ? s.s_mask : (const unsigned char*)nullptr, s.cap);
-        HIPCHK(h, hipGetLastError());
+        if (s.cap <= 0 || rc != 0) continue;
+        auto body = [&]() -> int {
+            HIPCHK(h, hipSetDevice(s.device));
+            const unsigned char* dm = nullptr;
+            int r = stage_mask(h, s, mask, &dm);
+            if (r != 0) return r;
+            hipLaunchKernelGGL(k_shift, dim3(s.cap), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem.cap, N, dm, s.cap, (int)C_U);
+            if (s.mem.lam)
+                hipLaunchKernelGGL(k_shift, dim3(s.cap), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem.lam, N, dm, s.cap, 0);
+            HIPCHK(h, hipGetLastError());
+            return 0;
+        };
+        rc = body();
     }
-    for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
-    }
-    return 0;
+    sync_all(h);
+    return rc;
 }
 
 int mpc_batch_track_set_shift(mpc_batch_t* h, int on) {
@@ -1073,55 +1187,60 @@ int mpc_batch_track_set_shift(mpc_batch_t* h, int on) {
 int mpc_batch_get(mpc_batch_t* h, int B, double* xtraj, double* utraj, double* pi) {
     if (!h || B < 1 || B > h->capacity) return -1;
     const int N = h->spec.N;
-
     DeviceGuard device_guard;
+    int rc = 0;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
-        if (n <= 0) continue;
+        if (n <= 0 || rc != 0) continue;
         const size_t o = (size_t)s.first;
-        HIPCHK(h, hipSetDevice(s.device));
-        if (xtraj) {
-            unpack_iter(s.mem, N, s.stream, s.s_xt, N + 1, 3, (int)R_X, n);
-            HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
-        }
-        if (utraj) {
-            unpack_iter(s.mem, N, s.stream, s.s_ut, N, 2, (int)R_U, n);
-            HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
-        }
-        if (pi) {
-            unpack_iter(s.mem, N, s.stream, s.s_pi, N, 3, (int)R_PI, n);
-            HIPCHK(h, hipMemcpyAsync(pi + 3 * N * o, s.s_pi, sizeof(double) * 3 * N * n, hipMemcpyDeviceToHost, s.stream));
-        }
-        HIPCHK(h, hipGetLastError());
+        auto body = [&]() -> int {
+            HIPCHK(h, hipSetDevice(s.device));
+            int r = ensure_staging(h, s, true);
+            if (r != 0) return r;
+            if (xtraj) {
+                unpack_iter(s.mem, N, s.stream, s.s_xt, N + 1, 3, (int)C_X, n);
+                HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
+            }
+            if (utraj) {
+                unpack_iter(s.mem, N, s.stream, s.s_ut, N, 2, (int)C_U, n);
+                HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+            }
+            if (pi) {
+                unpack_iter(s.mem, N, s.stream, s.s_pi, N, 3, (int)C_PI, n);
+                HIPCHK(h, hipMemcpyAsync(pi + 3 * N * o, s.s_pi, sizeof(double) * 3 * N * n, hipMemcpyDeviceToHost, s.stream));
+            }
+            HIPCHK(h, hipGetLastError());
+            return 0;
+        };
+        rc = body();
     }
-    for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
-    }
-    return 0;
+    sync_all(h);
+    return rc;
 }
 
 int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u) {
     if (!h || B < 1 || B > h->capacity || !x || !u) return -1;
     DeviceGuard device_guard;
+    int rc = 0;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
-        if (n <= 0) continue;
+        if (n <= 0 || rc != 0) continue;
         const size_t o = (size_t)s.first;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipMemcpyAsync(s.s_x0, x + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
-        HIPCHK(h, hipMemcpyAsync(s.s_u0, u + 2 * o, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s.stream));
-        hipLaunchKernelGGL(k_sim_step, dim3((n + 255) / 256), dim3(256), 0, s.stream, h->consts, s.s_x0, s.s_u0, n);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(x + 3 * o, s.s_x0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s.stream));
+        auto body = [&]() -> int {
+            HIPCHK(h, hipSetDevice(s.device));
+            int r = ensure_staging(h, s, false);
+            if (r != 0) return r;
+            HIPCHK(h, hipMemcpyAsync(s.s_x0, x + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(h, hipMemcpyAsync(s.s_u0, u + 2 * o, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s.stream));
+            hipLaunchKernelGGL(k_sim_step, dim3((n + 255) / 256), dim3(256), 0, s.stream, h->consts, s.s_x0, s.s_u0, n);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(x + 3 * o, s.s_x0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s.stream));
+            return 0;
+        };
+        rc = body();
     }
-    for (Shard& s : h->shards) {
-        if (s.cap <= 0) continue;
-        HIPCHK(h, hipSetDevice(s.device));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
-    }
-    return 0;
+    sync_all(h);
+    return rc;
 }
 
 double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
@@ -1138,7 +1257,7 @@ double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
 static Track make_track(const mpc_batch* h, const Shard& s) {
     Track tr;
     tr.sref = s.t_sref; tr.iref = s.t_iref; tr.M = s.t_M; tr.Mi = s.t_Mi;
-    tr.x = s.t_x; tr.u = s.t_u; tr.idx = s.t_idx;
+    tr.x = s.t_x; tr.u = s.t_u; tr.idx = s.t_idx; tr.yref = s.t_yref; tr.yref_e = s.t_yrefe;
     tr.density = h->t_density; tr.limit = h->t_limit; tr.lookahead = 1;
     return tr;
 }
@@ -1150,10 +1269,11 @@ int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, in
         if (s.cap <= 0) continue;
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
+        if (s.t_sref) s.dev_bytes -= sizeof(double) * (3 * (size_t)s.t_M + 2 * (size_t)s.t_Mi);
         (void)hipFree(s.t_sref); (void)hipFree(s.t_iref);
         s.t_sref = s.t_iref = nullptr;
-        HIPCHK(h, hipMalloc(&s.t_sref, sizeof(double) * 3 * M));
-        HIPCHK(h, hipMalloc(&s.t_iref, sizeof(double) * 2 * Mi));
+        DEVALLOC(h, s, s.t_sref, sizeof(double) * 3 * M);
+        DEVALLOC(h, s, s.t_iref, sizeof(double) * 2 * Mi);
         HIPCHK(h, hipMemcpy(s.t_sref, state_refs, sizeof(double) * 3 * M, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(s.t_iref, input_refs, sizeof(double) * 2 * Mi, hipMemcpyHostToDevice));
         s.t_M = M; s.t_Mi = Mi;
@@ -1163,52 +1283,79 @@ int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, in
 
 int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, double v_ref) {
     if (!h || B < 1 || B > h->capacity || !x_init || !(T > 0.0) || !(v_ref > 0.0)) return -1;
+    // T only sizes the waypoint windows (density, limit), exactly as in the reference, where the
+    // constructor's T is ignored by the solver and the plant step: those run on the generated
+    // variant's own time step (src/optimizer.cpp:117-119; the reference's own launch files pass
+    // T = 0.1 to the Ts = 0.05 variant).  So T != spec.Ts is legal here too.
     // Optimizer::Optimizer (src/optimizer.cpp:128, 174) and find_next_waypoint's statics (:387-391)
     h->t_density = 1.0 / T / v_ref;
     const double v_lim = v_ref > 0.3 ? 0.35 : v_ref;
     h->t_limit = (int)floor(3.95 / (v_lim * T));
+    const int N = h->spec.N;
     DeviceGuard device_guard;
     for (Shard& s : h->shards) {
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        s.t_n = 0;
         if (n <= 0) continue;
         if (!s.t_sref) { h->err = "mpc_batch_track_init: call mpc_batch_track_set_path first"; return -1; }
         HIPCHK(h, hipSetDevice(s.device));
         if (!s.t_x) {
-            HIPCHK(h, hipMalloc(&s.t_x, sizeof(double) * 3 * s.S));
-            HIPCHK(h, hipMalloc(&s.t_u, sizeof(double) * 2 * s.S));
-            HIPCHK(h, hipMalloc(&s.t_idx, sizeof(int) * 4 * s.S));
+            DEVALLOC(h, s, s.t_x, sizeof(double) * 3 * s.S);
+            DEVALLOC(h, s, s.t_u, sizeof(double) * 2 * s.S);
+            DEVALLOC(h, s, s.t_idx, sizeof(int) * 4 * s.S);
+            DEVALLOC(h, s, s.t_yref, sizeof(double) * 5 * N * s.S);
+            DEVALLOC(h, s, s.t_yrefe, sizeof(double) * 3 * s.S);
         }
+        HIPCHK(h, hipMemsetAsync(s.t_x, 0, sizeof(double) * 3 * s.S, s.stream));
         HIPCHK(h, hipMemcpyAsync(s.t_x, x_init + 3 * (size_t)s.first, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
         HIPCHK(h, hipMemsetAsync(s.t_u, 0, sizeof(double) * 2 * s.S, s.stream));
         HIPCHK(h, hipMemsetAsync(s.t_idx, 0, sizeof(int) * 4 * s.S, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
+        s.t_n = n;
     }
     return 0;
 }
 
 int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u, int* target, int* status) {
     if (!h || B < 1 || B > h->capacity || n_ticks < 0) return -1;
+    const int N = h->spec.N;
     DeviceGuard device_guard;
-    for (Shard& s : h->shards) {
+    for (Shard& s : h->shards) {   // validate before anything is enqueued
         const int n = B - s.first < s.cap ? B - s.first : s.cap;
         if (n <= 0) continue;
         if (!s.t_x) { h->err = "mpc_batch_track_run: call mpc_batch_track_init first"; return -1; }
-        HIPCHK(h, hipSetDevice(s.device));
-        const Track tr = make_track(h, s);
-        const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
-        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
-        for (int t = 0; t < n_ticks; ++t) {
-            hipLaunchKernelGGL(k_track_select, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
-            int rc = enqueue_core(h, s, n, s.stream);
-            if (rc != 0) return rc;
-            hipLaunchKernelGGL(k_track_advance, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, n);
-            if (h->track_shift)
-                hipLaunchKernelGGL(k_shift, dim3(n), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem, h->spec.N,
-                                   (const unsigned char*)nullptr, n);
-        }
-        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
-        HIPCHK(h, hipGetLastError());
+        if (n > s.t_n) { h->err = "mpc_batch_track_run: B exceeds the vehicles given to mpc_batch_track_init"; return -1; }
     }
+    auto body = [&]() -> int {
+        for (Shard& s : h->shards) {
+            const int n = B - s.first < s.cap ? B - s.first : s.cap;
+            if (n <= 0) continue;
+            HIPCHK(h, hipSetDevice(s.device));
+            const Track tr = make_track(h, s);
+            const dim3 wgrid((n + MPC_WAVE - 1) / MPC_WAVE), wblk(MPC_WAVE);
+            const unsigned pgrid = (unsigned)(((size_t)n * (N + 1) + 255) / 256);
+            HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+            for (int t = 0; t < n_ticks; ++t) {
+                hipLaunchKernelGGL(k_track_select, wgrid, wblk, 0, s.stream, tr, n);
+                hipLaunchKernelGGL(k_track_pack, dim3(pgrid), dim3(256), 0, s.stream, tr, N, n);
+                int rc = enqueue_solve(h, s, n, s.t_x, s.t_yref, s.t_yrefe, s.d_u0, nullptr, nullptr, nullptr, nullptr, s.stream);
+                if (rc != 0) return rc;
+                hipLaunchKernelGGL(k_track_advance, wgrid, wblk, 0, s.stream, h->consts, s.mem, tr, (const double*)s.d_u0, n);
+                if (h->track_shift) {
+                    hipLaunchKernelGGL(k_shift, dim3(n), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem.cap, N,
+                                       (const unsigned char*)nullptr, n, (int)C_U);
+                    if (s.mem.lam)
+                        hipLaunchKernelGGL(k_shift, dim3(n), dim3(MPC_SHIFT_THREADS), 0, s.stream, s.mem.lam, N,
+                                           (const unsigned char*)nullptr, n, 0);
+                }
+            }
+            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+            HIPCHK(h, hipGetLastError());
+        }
+        return 0;
+    };
+    const int rc = body();
+    if (rc != 0) { sync_all(h); return rc; }
     double worst = 0.0;
     std::vector<int> idx4;
     for (Shard& s : h->shards) {
@@ -1266,19 +1413,41 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4) {
     }
     return 0;
 }
-// Development/diagnostic: live-instance counts at the start of phases 1..7 of the last solve
-// on the first shard (phase schedule of k_phase / k_compact).
-int mpc_batch_debug_phase_counts(mpc_batch_t* h, int* out8) {
-    if (!h || !out8 || h->shards.empty()) return -1;
-    Shard& s = h->shards[0];
+
+int mpc_batch_debug_linearize(mpc_batch_t* h, int B, const double* yref, const double* yref_e, double* out) {
+    if (!h || B < 1 || B > h->capacity || !yref || !yref_e || !out) return -1;
+    const int N = h->spec.N;
     DeviceGuard device_guard;
-    HIPCHK(h, hipSetDevice(s.device));
-    HIPCHK(h, hipStreamSynchronize(s.stream));
-    HIPCHK(h, hipMemcpy(out8, s.phase_ints, MPC_MAX_PHASES * sizeof(int), hipMemcpyDeviceToHost));
+    for (Shard& s : h->shards) {
+        const int n = B - s.first < s.cap ? B - s.first : s.cap;
+        if (n <= 0) continue;
+        const size_t o = (size_t)s.first;
+        HIPCHK(h, hipSetDevice(s.device));
+        int rc = ensure_staging(h, s, false);
+        if (rc != 0) return rc;
+        double* d_out = nullptr;
+        const size_t ob = sizeof(double) * 24 * (size_t)n * (N + 1);
+        HIPCHK(h, hipMalloc((void**)&d_out, ob));
+        hipError_t e = hipMemcpyAsync(s.s_yref, yref + 5 * N * o, sizeof(double) * 5 * N * n, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.s_yrefe, yref_e + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) {
+            const size_t tot = (size_t)n * (N + 1);
+            hipLaunchKernelGGL(k_debug_lin, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, s.stream, h->consts, s.mem,
+                               (const double*)s.s_yref, (const double*)s.s_yrefe, n, d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out + 24 * o * (N + 1), d_out, ob, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        else (void)hipStreamSynchronize(s.stream);
+        (void)hipFree(d_out);
+        if (e != hipSuccess) { h->err = std::string("mpc_batch_debug_linearize: ") + hipGetErrorString(e); return -2; }
+    }
     return 0;
 }
-// Device time of the first (dense, HBM-bound) k_phase launch of the last solve on the first
-// shard, from HIP events on the launch stream; synchronises.  Used by bench.py for the roofline.
+
+// Device time of the dominant solve kernel of the last solve on the first shard (k_wave, or the
+// dense first k_phase launch of the lane model), from HIP events on the launch stream;
+// synchronises.  Used by bench.py for the roofline.
 double mpc_batch_last_phase0_ms(mpc_batch_t* h) {
     if (!h || h->shards.empty()) return -1.0;
     Shard& s = h->shards[0];
@@ -1287,6 +1456,11 @@ double mpc_batch_last_phase0_ms(mpc_batch_t* h) {
         hipEventElapsedTime(&ms, s.ev_ph[0], s.ev_ph[1]) != hipSuccess)
         return -1.0;
     return ms;
+}
+size_t mpc_batch_device_bytes(const mpc_batch_t* h) {
+    size_t tot = 0;
+    if (h) for (const Shard& s : h->shards) tot += s.dev_bytes;
+    return tot;
 }
 int mpc_batch_horizon(const mpc_batch_t* h) { return h ? h->spec.N : -1; }
 int mpc_batch_capacity(const mpc_batch_t* h) { return h ? h->capacity : -1; }

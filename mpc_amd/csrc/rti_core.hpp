@@ -26,6 +26,8 @@
 
 #include <type_traits>
 
+#include "../../include/mpc_hpipm_args.h"
+
 #if defined(__HIPCC__)
 #define MPC_HD __host__ __device__ __forceinline__
 #define MPC_SWEEP __host__ __device__ __forceinline__
@@ -87,17 +89,19 @@ enum : int {
 };
 
 struct Mem {
-    char* slab;          // n_waves blocks of wave_bytes each
+    char* slab;          // lane model only: n_waves blocks of wave_bytes each (null until the first lane-model solve)
     size_t wave_bytes;   // (N+1) * MPC_RPS * 512
     int *STATUS, *QPITER, *DIAG;   // [S] each
     int *SQPITER, *ACTIVE;         // [S] each, full SQP only: QPs solved so far, still iterating
     double* NLPRES;                // [S][4] last NLP residuals (stat, eq, ineq, comp), full SQP only
-    // AoS capsule of the wave model (null: the iterate lives in the slab rows R_X, R_U, R_PI):
-    // cap[instance][stage 0..N][MPC_CAP] = x 3, u 2, pi 3, lam 8 — lane k of a wavefront reads
-    // and writes one contiguous 64-B line (x, u, pi), fully coalesced across the wave.
+    // The capsules (the iterate every <name>_acados_solve starts from), AoS:
+    // cap[instance][stage 0..N][MPC_CAP] = x 3, u 2, pi 3 — the lane that owns a stage reads and
+    // writes one contiguous 64-B line, fully coalesced across the wave.
     double* cap;
+    double* lam;         // [instance][stage 0..N][8] bound multipliers, full-SQP handles only (else null)
+    double* u0;          // [S][2] u_0 of the last solve (the previous one where the QP failed)
 };
-enum : int { MPC_CAP = 16, C_X = 0, C_U = 3, C_PI = 5, C_LAM = 8 };
+enum : int { MPC_CAP = 8, C_X = 0, C_U = 3, C_PI = 5 };
 
 // MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK: include/mpc_batch.h
 
@@ -868,7 +872,7 @@ struct Lane : Algebra {
         double alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
         // conditional predictor-corrector: fall back to pure centering
         const double mu_aff1 = (s.n.musum + alpha * fc.s1 + (alpha * alpha) * fc.s2) * nci;
-        if (mu_aff1 > 2.0 * mu_aff0) {
+        if (mu_aff1 > MPC_IPM_COND_PRED_CORR_FAC * mu_aff0) {
             mode = 2;
             sweep_bw(2, sigma_mu);
             sweep_fw<true>(2, sigma_mu, fc);
@@ -878,7 +882,7 @@ struct Lane : Algebra {
         if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
         double a_upd = alpha;
-        if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
+        if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * MPC_IPM_STEP_SCALE_LO + a_upd * MPC_IPM_STEP_SCALE_HI);
         sweep_bu<false>(mode, sigma_mu, a_upd, s.n);
         s.mu = s.n.musum * nci;
         ++s.kk;

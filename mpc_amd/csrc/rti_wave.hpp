@@ -1133,13 +1133,13 @@ struct Wave : Algebra {
             const double alpha = o.alpha;
             if (mode == 1) {
                 const double mu_aff1 = (musum + alpha * o.s1 + (alpha * alpha) * o.s2) * nc_inv();
-                o.redo_centering = mu_aff1 > 2.0 * mu_aff0;
+                o.redo_centering = mu_aff1 > MPC_IPM_COND_PRED_CORR_FAC * mu_aff0;
             }
             o.accepted = !o.redo_centering && !(may_retry && o.lin_scan);
             if (o.accepted) {
                 // COMPUTE step: variables move by the damped step length (d_ocp_qp_ipm_solve)
                 double a_upd = alpha;
-                if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * 0.99 + a_upd * 0.9999999);
+                if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * MPC_IPM_STEP_SCALE_LO + a_upd * MPC_IPM_STEP_SCALE_HI);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const double aj = a_upd * bf(j), lmin = c.lam_min * bf(j);   // no bound: lam stays 0, t stays 1

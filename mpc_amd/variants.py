@@ -15,7 +15,7 @@ HPIPM_SPEED_ABS, HPIPM_SPEED, HPIPM_BALANCE, HPIPM_ROBUST = 0, 1, 2, 3
 
 SUCCESS, NAN_DETECTED, MAXITER, MINSTEP, QP_FAILURE = 0, 1, 2, 3, 4
 
-MAX_N = 128
+MAX_N = 127
 
 
 class OcpSpec(ctypes.Structure):

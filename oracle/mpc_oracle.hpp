@@ -33,50 +33,37 @@
 #include <vector>
 
 #include "../include/mpc_batch.h"
+#include "../include/mpc_hpipm_args.h"
 
 namespace mpc_oracle {
 
 constexpr int NX = MPC_NX, NU = MPC_NU, NV = NX + NU, NB = 4, NC = 2 * NB;
 
 // ----------------------------------------------------------------------------------
-// HPIPM arguments: d_ocp_qp_ipm_arg_set_default(mode) + acados overrides.
-// Every constant that could not be re-checked against upstream offline lives here.
+// HPIPM arguments: d_ocp_qp_ipm_arg_set_default(BALANCE) + acados overrides.  The values live in
+// include/mpc_hpipm_args.h, shared with the product so that a correction is made once.
 // ----------------------------------------------------------------------------------
 struct IpmArg {
-    double mu0 = 1e1;
-    double alpha_min = 1e-12;
-    double res_g_max = 1e-6, res_b_max = 1e-8, res_d_max = 1e-8, res_m_max = 1e-8;
+    double mu0 = MPC_IPM_MU0;
+    double alpha_min = MPC_IPM_ALPHA_MIN;
+    double res_g_max = MPC_IPM_RES_G_MAX, res_b_max = MPC_IPM_RES_B_MAX, res_d_max = MPC_IPM_RES_D_MAX,
+           res_m_max = MPC_IPM_RES_M_MAX;
     int iter_max = 50;  // acados qp_iter_max (acados_solver_mobile_robot.c:682)
-    int pred_corr = 1, cond_pred_corr = 1;
-    int itref_pred_max = 0, itref_corr_max = 2;
-    double reg_prim = 1e-15;
-    int lq_fact = 1;
-    double lam_min = 1e-16, t_min = 1e-16, tau_min = 1e-16;
-    double thr0 = 1e-1;          // OCP_QP_INIT_VAR cold-start threshold
-    double lq_switch_tol = 1e-5; // OCP_QP_IPM_DELTA_STEP: refactorise with LQ above this
-    double cond_pred_corr_fac = 2.0;
-    double step_scale_lo = 0.99, step_scale_hi = 0.9999999;  // UPDATE_VAR_QP
+    int pred_corr = MPC_IPM_PRED_CORR, cond_pred_corr = MPC_IPM_COND_PRED_CORR;
+    int itref_pred_max = MPC_IPM_ITREF_PRED_MAX, itref_corr_max = MPC_IPM_ITREF_CORR_MAX;
+    double reg_prim = MPC_IPM_REG_PRIM;
+    int lq_fact = MPC_IPM_LQ_FACT;
+    double lam_min = MPC_IPM_LAM_MIN, t_min = MPC_IPM_T_MIN, tau_min = MPC_IPM_TAU_MIN;
+    double thr0 = MPC_IPM_THR0;                    // OCP_QP_INIT_VAR cold-start threshold
+    double lq_switch_tol = MPC_IPM_LQ_SWITCH_TOL;  // OCP_QP_IPM_DELTA_STEP: refactorise with LQ above this
+    double cond_pred_corr_fac = MPC_IPM_COND_PRED_CORR_FAC;
+    double step_scale_lo = MPC_IPM_STEP_SCALE_LO, step_scale_hi = MPC_IPM_STEP_SCALE_HI;  // UPDATE_VAR_QP
 };
 
-inline IpmArg ipm_arg_for_mode(int mode, int iter_max) {
+// Only BALANCE (the reference's mode, acados_solver_mobile_robot.c:670) is restated; the product
+// rejects every other mode (mpc_amd/csrc/consts.hpp spec_problem).
+inline IpmArg ipm_arg_for_mode(int /*mode*/, int iter_max) {
     IpmArg a;
-    switch (mode) {
-        case MPC_HPIPM_SPEED_ABS:
-        case MPC_HPIPM_SPEED:
-            a.res_g_max = a.res_b_max = a.res_d_max = 1e0;
-            a.res_m_max = 1e-8;
-            a.itref_corr_max = 0;
-            a.lq_fact = 0;
-            break;
-        case MPC_HPIPM_ROBUST:
-            a.mu0 = 1e2;
-            a.itref_corr_max = 4;
-            a.lq_fact = 2;
-            break;
-        case MPC_HPIPM_BALANCE:
-        default:
-            break;
-    }
     a.iter_max = iter_max;
     return a;
 }

@@ -20,7 +20,8 @@ extern "C" int hostcore_rti_batch(const mpc_ocp_spec_t* spec, int B, const doubl
     std::vector<double> slab(slab_bytes_for(N, B) / sizeof(double), 0.0);
     std::vector<int> islab(islab_ints_for(B), 0);
     (void)S;
-    Mem m = make_mem(reinterpret_cast<char*>(slab.data()), islab.data(), B, N);
+    Mem m = make_mem(islab.data(), B, N);
+    m.slab = reinterpret_cast<char*>(slab.data());
     double* D = slab.data();
     for (size_t i = 0; i < (size_t)B; ++i) {
         for (int q = 0; q < 3; ++q) {

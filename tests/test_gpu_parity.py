@@ -475,45 +475,57 @@ def test_config2_batch_4096_n25_variant(oracle):
     solver.close()
 
 
-@pytest.mark.parametrize("name,box", [("mobile_robot_25", 0.1), ("mobile_robot", 0.05), ("park", 0.2)])
+@pytest.mark.parametrize("name,box", [("mobile_robot_25", 0.1), ("mobile_robot", 0.05), ("park", 0.2), ("mobile_robot_25", 0.03)])
 def test_active_state_bounds_stress(oracle, name, box):
     """Robustness of the parallel scans: state bounds tightened to a +-box around the start so that
     the x/y barrier terms (which enter J of the Riccati scan, I + C J ill-conditioned) are strongly
     active.  All three execution models must follow the oracle's IPM path (same status, same
-    iteration counts); the deviation is then set by the conditioning of the problem, not by the
-    model (the bar here is 1e-5; every model is within a factor ~1.2 of the others).  The wave
-    model's acceptance test on the linear-system residual falls back to the sequential recursions
-    where the scans are not accurate enough — flagged in DIAG, never on the unstressed workloads."""
+    iteration counts) and stay within north_star's 1e-6 of it on every solve.  Every tick starts
+    all models from the SAME iterate (the oracle's previous output, passed in explicitly): this is
+    the per-solve deviation.  (Measured finding, round 2: when each implementation is instead fed
+    its own previous output, the deviation of EVERY model — the sequential lane model included —
+    grows about tenfold per tick on the +-5 cm box, 1e-10 -> 3e-9 -> 3e-7 -> 1.7e-6: the RTI map
+    itself amplifies rounding differences on such a box; the closed-sequence drift is printed.)
+    The wave model's acceptance test on the linear-system residual falls back to the sequential
+    recursions where the scans are not accurate enough — flagged in DIAG, never on the
+    unstressed workloads."""
     B = 1024
     sp, wl = workload.make(name, B)
     x0, yref, yref_e = (a.copy() for a in wl.tick(0))
     shift = x0[:, :2].copy()
     x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
     sp = sp.copy(lbx=(-box, -box), ubx=(box, box))
-    solvers = {}
+    solvers, drift = {}, {}
     for model in ("wave", "waveseq", "lane"):
         solvers[model] = capi.BatchSolver(sp, B)
         solvers[model].set_model(model)
-    xo = uo = None
-    fallbacks = 0
+        drift[model] = capi.BatchSolver(sp, B)
+        drift[model].set_model(model)
+    xo, uo = np.zeros((B, sp.N + 1, 3)), np.zeros((B, sp.N, 2))
+    fallbacks, worst, worst_drift = 0, 0.0, 0.0
     for t in range(4):
         ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
-        xo, uo = ro["xtraj"], ro["utraj"]
         for model, s in solvers.items():
-            rg = s.solve(x0, yref, yref_e)
-            _, ug, _ = s.get(B, want_pi=False)
+            rg = s.solve(x0, yref, yref_e, xtraj=xo, utraj=uo)
             assert np.array_equal(ro["status"], rg["status"]), (model, t)
             assert (ro["qp_iter"] == rg["qp_iter"]).mean() >= 0.999, (model, t)
             same = ro["qp_iter"] == rg["qp_iter"]
-            assert np.abs(ug - uo)[same].max() < 1e-5, (model, t)
+            dev = max(np.abs(rg["utraj"] - ro["utraj"])[same].max(), np.abs(rg["xtraj"] - ro["xtraj"])[same].max())
+            worst = max(worst, dev)
+            assert dev < TOL_HARD, (model, t, dev)
             dg = s.get_diag(B)
             if model == "wave":
                 fallbacks += int(((dg & 4) != 0).sum())
             else:
                 assert ((dg & 4) == 0).all()
-    for s in solvers.values():
+            drift[model].solve(x0, yref, yref_e)
+            _, ud, _ = drift[model].get(B, want_pi=False)
+            worst_drift = max(worst_drift, np.abs(ud - ro["utraj"]).max())
+        xo, uo = ro["xtraj"], ro["utraj"]
+    for s in list(solvers.values()) + list(drift.values()):
         s.close()
-    print(f"{name} box {box}: scan fallbacks flagged on {fallbacks} instance-ticks of {4 * B}")
+    print(f"{name} box {box}: per-solve deviation {worst:.2e}, closed-sequence drift after 4 ticks {worst_drift:.2e}, "
+          f"scan fallbacks flagged on {fallbacks} instance-ticks of {4 * B}")
 
 
 def test_diag_is_clean_on_the_bench_workload():
@@ -716,3 +728,183 @@ def test_one_handle_per_thread_concurrently(oracle):
             xo, uo = ro["xtraj"], ro["utraj"]
             rg["xtraj"], rg["utraj"] = xg, ug
             _compare(ro, rg, B, min_same=0.99)
+
+
+def test_linearisation_matches_oracle(oracle):
+    """H5 / H7 / H8 / H9 directly: the QP data the preparation phase produces at
+    a warm iterate — A_k, B_k, b_k, the LINEAR_LS gradient and the BGH bound residuals — against
+    the oracle's dense restatement, stage by stage, to 1e-13 (the trig calls differ by <= 1-2 ulp
+    between ocml and glibc)."""
+    for name, B in (("mobile_robot", 48), ("park", 24), ("mobile_robot_50", 8)):
+        sp, wl = workload.make(name, B)
+        N = sp.N
+        solver = capi.BatchSolver(sp, B)
+        x0, yref, yref_e = wl.tick(0)
+        solver.solve(x0, yref, yref_e)
+        xt, ut, _ = solver.get(B, want_pi=False)
+        x1, yref1, yref_e1 = wl.tick(1)
+        lin = solver.debug_linearize(yref1, yref_e1)
+        worst = 0.0
+        for i in range(B):
+            ro = oracle.rti_debug(sp, x1[i], yref1[i], yref_e1[i], xt[i], ut[i])
+            A, Bm = ro["A"], ro["B"]
+            for k in range(N):
+                Ak = np.array([[1.0, 0.0, lin["ab"][i, k, 0]], [0.0, 1.0, lin["ab"][i, k, 1]], [0.0, 0.0, 1.0]])
+                Bk = np.array([[lin["ab"][i, k, 2], lin["ab"][i, k, 5]], [lin["ab"][i, k, 3], lin["ab"][i, k, 6]],
+                               [lin["ab"][i, k, 4], lin["ab"][i, k, 7]]])
+                worst = max(worst, np.abs(Ak - A[k]).max(), np.abs(Bk - Bm[k]).max())
+            worst = max(worst, np.abs(lin["b"][i, :N] - ro["b"]).max(), np.abs(lin["g"][i] - ro["g"]).max(),
+                        np.abs(lin["d"][i] - ro["d"]).max())
+            assert not lin["ab"][i, N].any() and not lin["b"][i, N].any() and not lin["d"][i, N].any()
+        assert worst < 1e-13, (name, worst)
+        solver.close()
+
+
+def test_config5_full_sqp_at_its_own_settings(oracle):
+    """BASELINE config 5 at its own settings on one GPU's share of the 1 M instances: 131072
+    perturbed instances, N = 50, full SQP with sqp_max_iter = 100 and nlp_tol = 1e-6 (the reference
+    JSON's nlp_solver_max_iter / nlp_solver_tol_*).  Size-independent properties on the whole batch
+    and the oracle on a seeded sample of 256."""
+    B = 131072
+    sp, wl = workload.make("mobile_robot", B, sqp_max_iter=100, nlp_tol=1e-6)
+    x0, yref, yref_e = wl.tick(0)
+    solver = capi.BatchSolver(sp, B)
+    r = solver.solve(x0, yref, yref_e)
+    sit, res = solver.get_sqp(B)
+    xt, ut, _ = solver.get(B, want_pi=False)
+    st = r["status"]
+    assert np.isin(st, (0, 2)).all(), np.unique(st)
+    ok = st == 0
+    assert ok.mean() > 0.9
+    assert (res[ok] < sp.nlp_tol).all()                       # converged = all four residuals below the tolerance
+    assert (sit[~ok] == 100).all() and (sit[ok] < 100).all() and (sit[ok] >= 1).all()
+    eps = 1e-6                                               # bounds hold to the tolerance of the exit test
+    assert (ut[ok][:, :, 0] <= sp.ubu[0] + eps).all() and (ut[ok][:, :, 0] >= sp.lbu[0] - eps).all()
+    assert (ut[ok][:, :, 1] <= sp.ubu[1] + eps).all() and (ut[ok][:, :, 1] >= sp.lbu[1] - eps).all()
+    assert np.abs(xt[ok][:, 0] - x0[ok]).max() < eps          # x0 constraint
+    assert np.array_equal(r["u0"], ut[:, 0])
+    idx = np.random.Generator(np.random.PCG64(9)).choice(B, 256, replace=False)
+    ro = oracle.sqp_batch(sp, x0[idx], yref[idx], yref_e[idx])
+    assert np.array_equal(ro["status"], st[idx])
+    same = ro["sqp_iter"] == sit[idx]
+    assert same.mean() >= 0.98, same.mean()
+    assert np.abs(ro["utraj"] - ut[idx])[same].max() < TOL_PATH and np.abs(ro["xtraj"] - xt[idx])[same].max() < TOL_PATH
+    assert np.abs(ro["utraj"] - ut[idx]).max() < 1e-4         # an instance that stops one QP apart is still at the tolerance
+    # bitwise run-to-run
+    solver.reset()
+    r2 = solver.solve(x0, yref, yref_e)
+    sit2, _ = solver.get_sqp(B)
+    assert np.array_equal(r2["u0"], r["u0"]) and np.array_equal(sit2, sit) and np.array_equal(r2["status"], st)
+    solver.close()
+
+
+@pytest.mark.parametrize("model", ["wave", "lane"])
+def test_shift_on_the_largest_horizon(oracle, model):
+    """mpc_batch_shift on an N = MPC_MAX_N handle in both execution models (round-1 advisor finding:
+    the lane-only handle of the then-largest horizon had no capsule and faulted)."""
+    N = variants.MAX_N
+    B = 9
+    sp, wl = workload.make("mobile_robot", B, N=N)
+    s = capi.BatchSolver(sp, B)
+    s.set_model(model)
+    x0, yref, yref_e = wl.tick(0)
+    rg = s.solve(x0, yref, yref_e)
+    ro = oracle.rti_batch(sp, x0, yref, yref_e)
+    xt, ut, pi = s.get(B)
+    assert np.array_equal(ro["status"], rg["status"]) and np.abs(ro["utraj"] - ut).max() < TOL_HARD
+    s.shift()
+    xs, us, ps = s.get(B)
+    assert np.array_equal(xs[:, :-1], xt[:, 1:]) and np.array_equal(xs[:, -1], xt[:, -1])
+    assert np.array_equal(us[:, :-1], ut[:, 1:]) and np.array_equal(us[:, -1], ut[:, -1])
+    assert np.array_equal(ps[:, :-1], pi[:, 1:]) and np.array_equal(ps[:, -1], pi[:, -1])
+    s.close()
+
+
+def test_track_run_rejects_more_vehicles_than_initialised():
+    import os
+    from mpc_amd.optimizer import load_txt
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))
+    u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))
+    sp = variants.spec("mobile_robot_25")
+    solver = capi.BatchSolver(sp, 16)
+    solver.track_set_path(s, u)
+    solver.track_init(np.tile(s[0], (8, 1)), 0.1, 0.5)
+    assert (solver.track_run(2)["status"] == 0).all()
+    solver._track_B = 12                                          # more than track_init was given
+    with pytest.raises(capi.MpcError):
+        solver.track_run(1)
+    solver.close()
+
+
+@pytest.mark.parametrize("cap", [37, 65537])
+def test_two_shards_equal_one(oracle, cap):
+    """The in-process multi-shard path of the C-ABI (mpc_batch_create with several device ids; the
+    one-GPU box gives both shards device 0), ragged capacity: solve, get, reset(mask), shift,
+    sim_step and the device closed loop equal the single-shard handle bit for bit."""
+    import os
+    from mpc_amd.optimizer import load_txt
+    sp, wl = workload.make("mobile_robot_25", cap)
+    one = capi.BatchSolver(sp, cap, devices=[0])
+    two = capi.BatchSolver(sp, cap, devices=[0, 0])
+    for t in range(2):
+        x0, yref, yref_e = wl.tick(t)
+        r1 = one.solve(x0, yref, yref_e)
+        r2 = two.solve(x0, yref, yref_e)
+        for k in ("u0", "status", "qp_iter"):
+            assert np.array_equal(r1[k], r2[k]), (t, k)
+    g1, g2 = one.get(cap), two.get(cap)
+    assert all(np.array_equal(a, b) for a, b in zip(g1, g2))
+    if cap < 1000:
+        ro = oracle.rti_batch(sp, *wl.tick(0))
+        ro = oracle.rti_batch(sp, *wl.tick(1), ro["xtraj"], ro["utraj"])
+        assert np.abs(ro["utraj"] - g2[1]).max() < TOL_PATH
+    mask = np.zeros(cap, np.uint8); mask[::3] = 1; mask[-1] = 1
+    one.reset(mask); two.reset(mask)
+    one.shift(); two.shift()
+    g1, g2 = one.get(cap), two.get(cap)
+    assert all(np.array_equal(a, b) for a, b in zip(g1, g2))
+    assert not g2[0][-1].any() and g2[0][1].any()
+    xs = np.ascontiguousarray(wl.tick(0)[0]); us = np.tile([0.3, 0.1], (cap, 1))
+    assert np.array_equal(one.sim_step(xs, us), two.sim_step(xs, us))
+    x0, yref, yref_e = wl.tick(2)
+    xt = np.zeros((cap, sp.N + 1, 3)); ut = np.zeros((cap, sp.N, 2))
+    r1 = one.solve(x0, yref, yref_e, xtraj=xt, utraj=ut)
+    r2 = two.solve(x0, yref, yref_e, xtraj=xt, utraj=ut)
+    assert np.array_equal(r1["utraj"], r2["utraj"]) and np.array_equal(r1["xtraj"], r2["xtraj"])
+    if cap < 1000:
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        s = load_txt(os.path.join(gold, "state_refs_path150_head.txt"))
+        u = load_txt(os.path.join(gold, "input_refs_path150_head.txt"))
+        start = s[np.arange(cap) % 50] + 0.01
+        outs = []
+        for h in (one, two):
+            h.reset()
+            h.track_set_path(s, u)
+            h.track_init(start, 0.1, 0.5)
+            outs.append(h.track_run(12))
+        for k in ("x", "u", "target", "status"):
+            assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert (two.get_diag(cap) == one.get_diag(cap)).all()
+    one.close(); two.close()
+
+
+def test_wave_only_handle_owns_little_more_than_its_capsules():
+    """A handle that only runs the wave model holds the capsules (64 B per stage) and the small
+    per-instance arrays; the lane model's workspace and the host-pointer staging appear on first use."""
+    torch = pytest.importorskip("torch")
+    B = 65536
+    sp, wl = workload.make("mobile_robot", B)
+    solver = capi.BatchSolver(sp, B)
+    cap_bytes = B * (sp.N + 1) * 64
+    assert cap_bytes <= solver.device_bytes() < cap_bytes * 1.05          # 0.214 GB
+    x0, yref, yref_e = wl.tick(0)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a).to(dev) for a in (x0, yref, yref_e)]
+    torch.cuda.synchronize()
+    solver.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+    solver.last_kernel_ms()
+    assert solver.device_bytes() < cap_bytes * 1.05                       # the device entry point allocates nothing
+    solver.solve(x0, yref, yref_e)
+    assert solver.device_bytes() < cap_bytes * 1.05 + yref.nbytes * 1.1   # + host-pointer staging
+    solver.close()

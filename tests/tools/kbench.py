@@ -19,7 +19,7 @@ def run(name, B, ticks=5, check=True):
         a, b, c = (torch.from_numpy(v).to(dev) for v in (x0, yref, yref_e))
         torch.cuda.synchronize()
         solver.solve_device(B, a.data_ptr(), b.data_ptr(), c.data_ptr(), d_u0.data_ptr(), 0, 0, d_st.data_ptr(), d_it.data_ptr())
-        ms.append(solver.last_kernel_ms()); it = d_it.cpu().numpy(); its.append((it.mean(), it.max())); pc = solver.phase_counts(); dg = np.bincount(solver.get_diag(B), minlength=8)
+        ms.append(solver.last_kernel_ms()); it = d_it.cpu().numpy(); its.append((it.mean(), it.max())); pc = None; dg = np.bincount(solver.get_diag(B), minlength=8)
     print(f"{name} B={B}: ms/tick " + " ".join(f"{m:.2f}" for m in ms) + " | iters(mean,max) " + " ".join(f"{a:.1f}/{b}" for a, b in its) + f" | last phase counts {pc.tolist()} diag {dg.tolist()}", flush=True)
     if check:
         from tests import oracle_lib
