@@ -105,6 +105,30 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
                            const double* d_yref_e, double* d_u0, double* d_xtraj,
                            double* d_utraj, int* d_status, int* d_qp_iter, void* stream);
 
+/* The one entry point that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  It is mpc_batch_solve_device's SQP_RTI step (same kernels,
+ * same results) on capsules that live in a fixed array inside the library (one copy per GPU,
+ * 35 MiB, held until the process ends) instead of in a handle:
+ *   spec            as for mpc_batch_create; sqp_max_iter must be 1 (SQP_RTI)
+ *   cold != 0       the first B capsules start from the all-zero iterate (a fresh handle);
+ *   cold == 0       they start from the iterate the previous call ON THIS GPU left (a warm handle)
+ *   d_x0 [B][3], d_yref [B][N][5], d_yref_e [B][3]  device pointers, in
+ *   d_u0 [B][2] out (required), d_status [B], d_qp_iter [B] out (may be NULL)
+ *   stream          a hipStream_t (NULL = the null stream); the call is NOT synchronised.
+ * Limits: B * (N + 1) <= MPC_STATIC_MAX_LINES and B <= MPC_STATIC_MAX_B, i.e. 10280 instances at
+ * N = 50; larger batches are refused with -4 and a message on stderr.  Returns 0, -1 (bad
+ * argument), -2 (HIP error), -3 (no device), -4 (too large).  It calls no hipMalloc / hipFree or
+ * any allocating routine; the first call on a GPU looks up that GPU's copy of the array
+ * (hipGetSymbolAddress) and loads the kernels — make one call before starting a graph capture.
+ * Every call on a GPU shares that GPU's array and the array keeps the last call's iterates:
+ * calls that overlap on one GPU (different streams or threads) race; serialise them. */
+#define MPC_STATIC_MAX_LINES 524288 /* capsule lines (64 B each) of the static workspace */
+#define MPC_STATIC_MAX_B 262144     /* instances (status words) of the static workspace */
+int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const double* d_x0,
+                           const double* d_yref, const double* d_yref_e, double* d_u0,
+                           int* d_status, int* d_qp_iter, void* stream);
+
 /* Replaces mobile_robot_acados_reset(capsule, 1)
  * (acados_solver_mobile_robot.c:830-869; Optimizer::reset_solver,
  * include/optimizer.hpp:446-456): zero x, u, pi of the selected capsules.

@@ -26,7 +26,7 @@ EXPORTS = (
     "mpc_batch_last_kernel_ms", "mpc_batch_horizon", "mpc_batch_capacity",
     "mpc_batch_last_error", "mpc_batch_version", "mpc_batch_debug_linearize", "mpc_batch_device_bytes", "mpc_batch_last_phase0_ms",
     "mpc_batch_get_sqp", "mpc_batch_track_set_path", "mpc_batch_track_init", "mpc_batch_track_run", "mpc_batch_set_model", "mpc_batch_get_diag",
-    "mpc_batch_shift", "mpc_batch_track_set_shift",
+    "mpc_batch_shift", "mpc_batch_track_set_shift", "mpc_batch_solve_static",
 )
 
 
@@ -89,6 +89,7 @@ def lib():
     L.mpc_batch_shift.argtypes = [_vp, ctypes.POINTER(ctypes.c_ubyte)]
     L.mpc_batch_track_set_shift.argtypes = [_vp, ctypes.c_int]
     L.mpc_batch_get_diag.argtypes = [_vp, ctypes.c_int, _ip]
+    L.mpc_batch_solve_static.argtypes = [ctypes.POINTER(OcpSpec), ctypes.c_int, ctypes.c_int] + [_vp] * 6 + [_vp]
     L.mpc_batch_horizon.argtypes = [_vp]
     L.mpc_batch_capacity.argtypes = [_vp]
     L.mpc_batch_last_error.argtypes = [_vp]
@@ -111,6 +112,16 @@ def spec_variant(name):
     if lib().mpc_spec_variant(name.encode(), ctypes.byref(s)) != 0:
         raise MpcError(f"unknown variant {name!r}")
     return s
+
+
+STATIC_MAX_LINES, STATIC_MAX_B = 524288, 262144
+
+
+def solve_static(spec, B, cold, d_x0, d_yref, d_yref_e, d_u0, d_status=0, d_qp_iter=0, stream=0):
+    """mpc_batch_solve_static: the SQP-RTI step on the library's static capsules (no handle, no
+    allocation); raw device pointers (ints); asynchronous.  Returns the C return code."""
+    return lib().mpc_batch_solve_static(ctypes.byref(spec), B, 1 if cold else 0, d_x0, d_yref, d_yref_e, d_u0,
+                                        d_status or None, d_qp_iter or None, stream or None)
 
 
 class BatchSolver:

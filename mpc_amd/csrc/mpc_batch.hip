@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -841,29 +842,30 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     return 0;
 }
 
-// The wave-model solve: one launch that reads the C-ABI's arrays and the capsules and writes
-// them back.  io.x0 / yref / yref_e / u0 must be set.
-static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
-    const int N = h->spec.N;
-    const Mem& m = s.mem;
-    const bool sqp = h->spec.sqp_max_iter > 1;
-    // MPC_MODEL_WAVE_SEQ: sequential Riccati recursions under a lane predicate instead of
-    // the parallel scans (development / cross-check; RTI only)
-    const bool seq = model == MPC_MODEL_WAVE_SEQ && !sqp;
-    const int mi = h->spec.sqp_max_iter;
-    HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+// The wave-model launch: reads the C-ABI's arrays and the capsules and writes them back.
+// wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
+// (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
+static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st) {
+    const int N = c.N;
+    const bool sqp = sqp_max_iter > 1;
+    seq = seq && !sqp;
 #define MPC_LAUNCH_WAVE(X_)                                                                                               \
     do {                                                                                                                  \
         const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                        \
-        if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, h->consts, m, n, mi, wio);                 \
-        else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);          \
-        else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, h->consts, m, n, mi, wio);                    \
+        if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
+        else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);        \
+        else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                  \
     } while (0)
     if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
     else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
     else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
     else MPC_LAUNCH_WAVE(XBlock);
 #undef MPC_LAUNCH_WAVE
+}
+
+static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
+    HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ, st);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1462,6 +1464,82 @@ size_t mpc_batch_device_bytes(const mpc_batch_t* h) {
     if (h) for (const Shard& s : h->shards) tot += s.dev_bytes;
     return tot;
 }
+// ---- the entry point that allocates nothing (include/mpc_batch.h: mpc_batch_solve_static) ----
+// Its capsules and per-instance status words live in a file-scope device array instead of a
+// handle.  `scratch` is a host-side stand-in for the symbol, not a device address: the address
+// each GPU holds its copy at is looked up once per device (static_scratch) and only that pointer
+// is ever handed to kernels, hipMemsetAsync or copies.
+struct StaticScratch {
+    double cap[(size_t)MPC_STATIC_MAX_LINES * MPC_CAP];   // capsule lines [instance][stage 0..N][8]
+    int status[MPC_STATIC_MAX_B], qp_iter[MPC_STATIC_MAX_B], diag[MPC_STATIC_MAX_B];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
+#define MPC_STATIC_MAX_DEVICES 64
+static StaticScratch* g_scratch_ptr[MPC_STATIC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+// The current device's copy of `scratch` (set-up on the first call on that device), or null.
+static StaticScratch* static_scratch(int dev) {
+    if (dev < 0 || dev >= MPC_STATIC_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            fprintf(stderr, "mpc_batch_solve_static: hipGetSymbolAddress(scratch): %s\n", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = static_cast<StaticScratch*>(p);
+    }
+    return g_scratch_ptr[dev];
+}
+
+int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const double* d_x0, const double* d_yref,
+                           const double* d_yref_e, double* d_u0, int* d_status, int* d_qp_iter, void* stream) {
+    if (const char* why = spec_problem(spec)) {
+        fprintf(stderr, "mpc_batch_solve_static: %s\n", why);
+        return -1;
+    }
+    if (spec->sqp_max_iter != 1) {
+        fprintf(stderr, "mpc_batch_solve_static: SQP_RTI only (sqp_max_iter must be 1)\n");
+        return -1;
+    }
+    if (B < 1 || !d_x0 || !d_yref || !d_yref_e || !d_u0) {
+        fprintf(stderr, "mpc_batch_solve_static: B must be >= 1 and x0, yref, yref_e, u0 non-null\n");
+        return -1;
+    }
+    const int N = spec->N;
+    if (B > MPC_STATIC_MAX_B || (long long)B * (N + 1) > (long long)MPC_STATIC_MAX_LINES) {
+        fprintf(stderr, "mpc_batch_solve_static: B = %d at N = %d needs %lld capsule lines; the static workspace holds %d "
+                        "(and at most %d instances): use a handle (mpc_batch_create) for larger batches\n",
+                B, N, (long long)B * (N + 1), MPC_STATIC_MAX_LINES, MPC_STATIC_MAX_B);
+        return -4;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -3;
+    StaticScratch* sc = static_scratch(dev);
+    if (!sc) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    Mem m;
+    memset(&m, 0, sizeof(m));
+    m.cap = sc->cap;
+    m.STATUS = sc->status; m.QPITER = sc->qp_iter; m.DIAG = sc->diag;
+    if (cold) {   // the all-zero iterate of a fresh capsule (acados_solver_mobile_robot.c:703-729)
+        const hipError_t e = hipMemsetAsync(sc->cap, 0, sizeof(double) * MPC_CAP * (size_t)B * (N + 1), st);
+        if (e != hipSuccess) {
+            fprintf(stderr, "mpc_batch_solve_static: hipMemsetAsync: %s\n", hipGetErrorString(e));
+            return -2;
+        }
+    }
+    const WaveIO io = {d_x0, d_yref, d_yref_e, d_u0, d_status, d_qp_iter};
+    launch_wave(make_consts(*spec), m, B, 1, io, false, st);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "mpc_batch_solve_static: launch: %s\n", hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
 int mpc_batch_horizon(const mpc_batch_t* h) { return h ? h->spec.N : -1; }
 int mpc_batch_capacity(const mpc_batch_t* h) { return h ? h->capacity : -1; }
 const char* mpc_batch_last_error(const mpc_batch_t* h) { return h ? h->err.c_str() : "null handle"; }
