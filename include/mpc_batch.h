@@ -222,6 +222,7 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
 #define MPC_MODEL_LANE 1
 #define MPC_MODEL_WAVE 2
 #define MPC_MODEL_WAVE_SEQ 3
+#define MPC_MODEL_WAVE1 4
 int mpc_batch_set_model(mpc_batch_t* h, int model);
 
 /* Introspection used by bench/tests: kernel time of the last solve in ms

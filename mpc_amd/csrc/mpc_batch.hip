@@ -20,6 +20,7 @@
 
 #include "consts.hpp"
 #include "rti_wave.hpp"
+#include "rti_wave2.hpp"
 
 using namespace mpc;
 
@@ -251,6 +252,177 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         for (int q = 0; q < 3; ++q) ck[C_PI + q] = pin[q];
 #pragma unroll
         for (int q = 0; q < 8; ++q) lk[q] = lamn[q];
+    }
+}
+
+// The same step with TWO stages per lane (rti_wave2.hpp): lane k of a GW-lane group owns stages 2k
+// and 2k+1, 64 / GW OCPs per wavefront (N = 50: two).  Same I/O as k_wave: the lane reads and
+// writes two consecutive capsule lines (128 B) and two consecutive yref rows (80 B).
+template <int GW, bool SCAN, bool SQP>
+__global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
+    typedef Wave2<GW, SCAN> W;
+    constexpr int G = W::PER_BLOCK;
+    const int l = threadIdx.x;
+    const int g = l / GW, k = l % GW;
+    const size_t i = (size_t)blockIdx.x * G + g;
+    const int N = c.N;
+    const bool inst = i < (size_t)B;
+    const size_t ic = inst ? i : (size_t)B - 1;
+    __shared__ mc_d2 mc_lds[W::LDS_SLOTS * 64];   // product cache of the scans + parked per-stage state
+    W w(c, k, mc_lds + l);
+    double* ck[2];
+    double* lk[2];
+    bool on[2];
+    double xi[2][3], ui[2][2], x0b[3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = 2 * k + e;
+        const int jc = j <= N ? j : N;
+        on[e] = inst && j <= N;
+        ck[e] = m.cap + ((size_t)ic * (N + 1) + jc) * MPC_CAP;
+        lk[e] = SQP ? m.lam + ((size_t)ic * (N + 1) + jc) * 8 : nullptr;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xi[e][q] = on[e] ? ck[e][C_X + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ui[e][q] = (on[e] && j < N) ? ck[e][C_U + q] : 0.0;
+        const double* yr = j < N ? io.yref + ((size_t)ic * N + jc) * 5 : io.yref_e + (size_t)ic * 3;
+        double y[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) y[q] = (on[e] && (j < N || q < 3)) ? yr[q] : 0.0;
+        w.set_yref(e, y);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) x0b[q] = (inst && k == 0) ? io.x0[3 * ic + q] : 0.0;
+    const double u_prev0 = ui[0][0], u_prev1 = ui[0][1];
+    typename W::State s;
+    s.kk = 0; s.diag = 0; s.alpha = 1.0; s.mu = 0.0; s.musum = 0.0; s.open = false;
+    int status = 0;
+    if (!SQP) {
+        // ---- SQP_RTI: one linearisation, one QP, full step ----
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double xn[3];
+            w.linearize(e, xi[e], ui[e], xn);
+            w.cold_start(e, xi[e], ui[e], x0b);
+        }
+        w.begin(s);
+        for (;;) {
+            const bool go = inst && w.cont(s);
+            if (!w.x.any(go)) break;
+            if (go) w.iterate(s);
+        }
+        int hs;
+        if (s.kk == c.iter_max) hs = 1;
+        else if (s.alpha <= c.alpha_min) hs = 2;
+        else if (s.mu != s.mu) hs = 3;
+        else hs = 0;
+        const bool ok = (hs == 0 || hs == 1);
+        status = ok ? 0 : 4;
+        if (inst && k == 0) {
+            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag; m.STATUS[i] = status;
+            if (io.status) io.status[i] = status;
+            if (io.qp_iter) io.qp_iter[i] = s.kk;
+            // on a QP failure the previous u_0 stays in force
+            io.u0[2 * i] = ok ? w.s[0].z[0] : u_prev0; io.u0[2 * i + 1] = ok ? w.s[0].z[1] : u_prev1;
+        }
+        if (ok) {
+            double pio[2][3];
+            w.get_pi(pio);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!on[e]) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ck[e][C_X + q] = w.s[e].z[2 + q];
+                if (2 * k + e < N) {
+                    ck[e][C_U + 0] = w.s[e].z[0]; ck[e][C_U + 1] = w.s[e].z[1];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) ck[e][C_PI + q] = pio[e][q];
+                }
+            }
+        }
+        return;
+    }
+    // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update ----
+    double pin[2][3], lamn[2][8], res[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const bool midl = on[e] && 2 * k + e < N;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pin[e][q] = midl ? ck[e][C_PI + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lamn[e][q] = midl ? lk[e][q] : 0.0;
+    }
+    bool running = inst;
+    int sqp_it = 0, qp_it = 0, diag = 0;
+    status = 2;   // MAXITER unless a residual check passes
+    for (;;) {
+        if (running && sqp_it >= sqp_max_iter) running = false;   // MAXITER: no check after the last QP
+        if (running) {
+            double xn[2][3];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) w.linearize(e, xi[e], ui[e], xn[e]);
+            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, res);
+            if (res[0] < c.nlp_tol && res[1] < c.nlp_tol && res[2] < c.nlp_tol && res[3] < c.nlp_tol) {
+                status = 0;
+                running = false;
+            }
+        }
+        if (!w.x.any(running)) break;
+        if (running) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) w.cold_start(e, xi[e], ui[e], x0b);
+            w.begin(s);
+        }
+        for (;;) {
+            const bool go = running && w.cont(s);
+            if (!w.x.any(go)) break;
+            if (go) w.iterate(s);
+        }
+        if (running) {
+            int hs;
+            if (s.kk == c.iter_max) hs = 1;
+            else if (s.alpha <= c.alpha_min) hs = 2;
+            else if (s.mu != s.mu) hs = 3;
+            else hs = 0;
+            qp_it = s.kk;
+            diag |= s.diag;
+            ++sqp_it;
+            if (hs == 0 || hs == 1) {
+                w.get_pi(pin);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ui[e][0] = w.s[e].z[0]; ui[e][1] = w.s[e].z[1];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) xi[e][q] = w.s[e].z[2 + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) lamn[e][q] = W::has_bound(w.s[e], q & 3) ? w.s[e].bn.lam[q] : 0.0;
+                }
+            } else {
+                status = 4;
+                running = false;
+            }
+        }
+    }
+    if (inst && k == 0) {
+        m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
+        if (io.status) io.status[i] = status;
+        if (io.qp_iter) io.qp_iter[i] = qp_it;
+        io.u0[2 * i] = ui[0][0]; io.u0[2 * i + 1] = ui[0][1];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (!on[e]) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ck[e][C_X + q] = xi[e][q];
+        if (2 * k + e < N) {
+            ck[e][C_U + 0] = ui[e][0]; ck[e][C_U + 1] = ui[e][1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ck[e][C_PI + q] = pin[e][q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lk[e][q] = lamn[e][q];
+        }
     }
 }
 
@@ -768,6 +940,7 @@ static int pick_model(const mpc_batch* h) {
         if (strcmp(model_env, "lane") == 0) model = MPC_MODEL_LANE;
         else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
+        else if (strcmp(model_env, "wave1") == 0) model = MPC_MODEL_WAVE1;
     }
     if (model == MPC_MODEL_AUTO) model = MPC_MODEL_WAVE;
     return model;
@@ -845,7 +1018,8 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // The wave-model launch: reads the C-ABI's arrays and the capsules and writes them back.
 // wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
 // (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
-static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st) {
+static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
+                        bool one_stage_per_lane = false) {
     const int N = c.N;
     const bool sqp = sqp_max_iter > 1;
     seq = seq && !sqp;
@@ -856,16 +1030,34 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
         else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);        \
         else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                  \
     } while (0)
-    if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
-    else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
-    else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
-    else MPC_LAUNCH_WAVE(XBlock);
+#define MPC_LAUNCH_WAVE2(GW_)                                                                                             \
+    do {                                                                                                                  \
+        const int per = 64 / GW_;                                                                                         \
+        const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
+        if (sqp) hipLaunchKernelGGL((k_wave2<GW_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);             \
+        else if (seq) hipLaunchKernelGGL((k_wave2<GW_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+        else hipLaunchKernelGGL((k_wave2<GW_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                \
+    } while (0)
+    if (one_stage_per_lane) {
+        if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
+        else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
+        else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
+        else MPC_LAUNCH_WAVE(XBlock);
+    } else {
+        // two stages per lane as soon as that does not leave more lanes idle: N + 1 <= 16 fills a
+        // 16-lane group with one stage per lane (four OCPs per wavefront either way)
+        if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
+        else if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
+        else if (N + 1 <= 64) MPC_LAUNCH_WAVE2(32);
+        else MPC_LAUNCH_WAVE2(64);
+    }
 #undef MPC_LAUNCH_WAVE
+#undef MPC_LAUNCH_WAVE2
 }
 
 static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
     HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ, st);
+    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ, st, model == MPC_MODEL_WAVE1);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1395,7 +1587,7 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag) {
 }
 
 int mpc_batch_set_model(mpc_batch_t* h, int model) {
-    if (!h || model < MPC_MODEL_AUTO || model > MPC_MODEL_WAVE_SEQ) return -1;
+    if (!h || model < MPC_MODEL_AUTO || model > MPC_MODEL_WAVE1) return -1;
     h->model = model;
     return 0;
 }

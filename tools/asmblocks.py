@@ -3,7 +3,8 @@ usage: python tools/asmblocks.py <mangled-name-substring> [min_block_size]"""
 import re
 import sys
 
-path = "mpc_amd/csrc/_asm/mpc_batch-hip-amdgcn-amd-amdhsa-gfx950.s"
+import os
+path = os.environ.get("ASM", "mpc_amd/csrc/_asm/mpc_batch-hip-amdgcn-amd-amdhsa-gfx950.s")
 lines = open(path).read().split("\n")
 start = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and sys.argv[1] in l][0]
 end = [i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")][0]
