@@ -76,6 +76,9 @@ inline Consts make_consts(const mpc_ocp_spec_t& s) {
     c.lq_tol = MPC_IPM_LQ_SWITCH_TOL;
     c.sqp = s.sqp_max_iter > 1 ? 1 : 0;
     c.nlp_tol = s.nlp_tol;
+    for (int i = 0; i < 5; ++i) c.wgr[i] = c.wg[i] + c.reg_prim;
+    for (int i = 0; i < 3; ++i) c.wer[i] = c.we[i] + c.reg_prim;
+    c.nc_inv = 1.0 / (4 + 8 * (c.N - 1));
     c.scan_tol_P = kScanTolP;
     c.scan_tol_lin = kScanTolLin;
     return c;

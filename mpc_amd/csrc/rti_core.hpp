@@ -56,6 +56,10 @@ struct Consts {
     // wave model, acceptance tests of the parallel scans (fallback to the sequential recursion):
     double scan_tol_P;    // relative residual of the Riccati equation, stage by stage
     double scan_tol_lin;  // stationarity residual of the corrector's linear system (absolute)
+    // uniform values the wave kernels would otherwise compute with vector instructions and keep in
+    // vector registers for the whole solve (there is no scalar FP64 unit): wg + reg_prim,
+    // we + reg_prim, 1 / (number of one-sided bounds)
+    double wgr[5], wer[3], nc_inv;
 };
 
 // Workspace layout.  One contiguous block per wavefront (64 instances):
@@ -267,9 +271,9 @@ struct Algebra {
         g.M10 = ab.B01 * P.p00 + ab.B11 * P.p10 + ab.B21 * P.p20;
         g.M11 = ab.B01 * P.p10 + ab.B11 * P.p11 + ab.B21 * P.p21;
         g.M12 = ab.B01 * P.p20 + ab.B11 * P.p21 + ab.B21 * P.p22;
-        const double Huu00 = (c.wg[0] + c.reg_prim) + Gam0 + (g.M00 * ab.B00 + g.M01 * ab.B10 + g.M02 * ab.B20);
+        const double Huu00 = c.wgr[0] + Gam0 + (g.M00 * ab.B00 + g.M01 * ab.B10 + g.M02 * ab.B20);
         const double Huu10 = g.M10 * ab.B00 + g.M11 * ab.B10 + g.M12 * ab.B20;
-        const double Huu11 = (c.wg[1] + c.reg_prim) + Gam1 + (g.M10 * ab.B01 + g.M11 * ab.B11 + g.M12 * ab.B21);
+        const double Huu11 = c.wgr[1] + Gam1 + (g.M10 * ab.B01 + g.M11 * ab.B11 + g.M12 * ab.B21);
         g.id0 = rcp(Huu00);
         g.l10 = Huu10 * g.id0;
         g.id1 = rcp(Huu11 - g.l10 * Huu10);

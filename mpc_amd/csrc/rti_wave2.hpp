@@ -19,6 +19,10 @@
 #pragma once
 #include "rti_wave.hpp"
 
+#ifndef MPC_CACHE0_COND
+#define MPC_CACHE0_COND (GW < 64)
+#endif
+
 namespace mpc {
 
 template <int GW, bool SCAN>
@@ -29,6 +33,16 @@ struct Wave2 : Algebra {
     static constexpr bool GUARD = PER_BLOCK > 1;     // several OCPs per wavefront: scans need partner guards
     X x;
     int k, N, Nl;   // lane within the group, horizon, last lane that owns a stage (N / 2)
+    // The interior-point arguments are compile-time constants here (only HPIPM's BALANCE mode is
+    // implemented, include/mpc_hpipm_args.h), not kernel arguments held in ~30 scalar registers.
+    struct K {
+        static constexpr double mu0 = MPC_IPM_MU0, alpha_min = MPC_IPM_ALPHA_MIN;
+        static constexpr double res_g_max = MPC_IPM_RES_G_MAX, res_b_max = MPC_IPM_RES_B_MAX, res_d_max = MPC_IPM_RES_D_MAX,
+                                res_m_max = MPC_IPM_RES_M_MAX;
+        static constexpr double reg_prim = MPC_IPM_REG_PRIM, lam_min = MPC_IPM_LAM_MIN, t_min = MPC_IPM_T_MIN, tau_min = MPC_IPM_TAU_MIN;
+        static constexpr double thr0 = MPC_IPM_THR0, itref_tol_g = MPC_IPM_RES_G_MAX, lq_tol = MPC_IPM_LQ_SWITCH_TOL;
+        static constexpr double scan_tol_lin = 1e-8;   // = kScanTolLin (consts.hpp)
+    };
 
     struct Stg {
         bool act, mid, isN, is0;   // j <= N, j < N, j == N, j == 0
@@ -52,9 +66,9 @@ struct Wave2 : Algebra {
     // 12..14 = pi of both stages.
     // LDS budget: 40 KB per wavefront keeps four wavefronts (one per SIMD) on a CU.  GW = 64 has
     // six product levels: its level 0 (Psi itself) is recomputed by every scan instead of cached.
-    static constexpr bool CACHE0 = GW < 64;
+    static constexpr bool CACHE0 = MPC_CACHE0_COND;
     static constexpr int MC_SLOTS = (X::MC_LEVELS - (CACHE0 ? 0 : 1)) * MPC_MC_PAIRS;
-    static constexpr int PK0 = MC_SLOTS > 24 ? MC_SLOTS : 24;   // (the cache area also parks 24 slots during the Riccati scan)
+    static constexpr int PK0 = MC_SLOTS > 25 ? MC_SLOTS : 25;   // (the cache area also parks 25 slots during the Riccati scan)
     static constexpr int LDS_SLOTS = PK0 + 15;
     static_assert(LDS_SLOTS <= 40, "more than 40 KB of LDS per wavefront");
     int wdiag = 0;
@@ -144,6 +158,12 @@ struct Wave2 : Algebra {
                 v.x = s[e].bn.t[2 * q]; v.y = s[e].bn.t[2 * q + 1]; mc[(12 * e + 4 + q) * 64] = v;
                 v.x = s[e].ti[2 * q]; v.y = s[e].ti[2 * q + 1]; mc[(12 * e + 8 + q) * 64] = v;
             }
+        // the primal iterate z of both stages (10 doubles) waits in the slots of the affine step
+        // dza, which is dead between the corrector of one iteration and the predictor of the next
+        pk_st(8, s[0].z[0], s[0].z[1]); pk_st(9, s[0].z[2], s[0].z[3]); pk_st(10, s[0].z[4], s[1].z[0]);
+        pk_st(11, s[1].z[1], s[1].z[2]);
+        mc_d2 v; v.x = s[1].z[3]; v.y = s[1].z[4];
+        mc[24 * 64] = v;   // slot 24: the last slot of the cache area (PK0 >= 25) or the first dza... see static_assert
     }
     __device__ __forceinline__ void unpark_bounds() {
 #pragma unroll
@@ -155,6 +175,10 @@ struct Wave2 : Algebra {
                 v = mc[(12 * e + 4 + q) * 64]; s[e].bn.t[2 * q] = v.x; s[e].bn.t[2 * q + 1] = v.y;
                 v = mc[(12 * e + 8 + q) * 64]; s[e].ti[2 * q] = v.x; s[e].ti[2 * q + 1] = v.y;
             }
+        pk_ld(8, s[0].z[0], s[0].z[1]); pk_ld(9, s[0].z[2], s[0].z[3]); pk_ld(10, s[0].z[4], s[1].z[0]);
+        pk_ld(11, s[1].z[1], s[1].z[2]);
+        const mc_d2 v = mc[24 * 64];
+        s[1].z[3] = v.x; s[1].z[4] = v.y;
     }
     __device__ __forceinline__ void mc_store(int level_, const M3& M) const {
         if (!CACHE0 && level_ == 0) return;
@@ -200,10 +224,10 @@ struct Wave2 : Algebra {
             double tl = t.z[j] - c.lb[j];
             double tu = c.ub[j] - t.z[j];
             double zj = t.z[j];
-            if (tl < c.thr0) {
-                if (tu < c.thr0) { zj = 0.5 * (c.lb[j] + c.ub[j]); tl = c.thr0; tu = c.thr0; }
-                else { tl = c.thr0; zj = c.lb[j] + c.thr0; }
-            } else if (tu < c.thr0) { tu = c.thr0; zj = c.ub[j] - c.thr0; }
+            if (tl < K::thr0) {
+                if (tu < K::thr0) { zj = 0.5 * (c.lb[j] + c.ub[j]); tl = K::thr0; tu = K::thr0; }
+                else { tl = K::thr0; zj = c.lb[j] + K::thr0; }
+            } else if (tu < K::thr0) { tu = K::thr0; zj = c.ub[j] - K::thr0; }
             // (every member is assigned exactly once, by value selects: stores to different members
             //  in the two arms of a branch get merged into one store through a computed address,
             //  which keeps the whole object in scratch memory)
@@ -214,8 +238,8 @@ struct Wave2 : Algebra {
             t.bn.t[4 + j] = hb ? tu : 1.0;
             t.ti[j] = hb ? til : 1.0;
             t.ti[4 + j] = hb ? tiu : 1.0;
-            t.bn.lam[j] = hb ? c.mu0 * til : 0.0;
-            t.bn.lam[4 + j] = hb ? c.mu0 * tiu : 0.0;
+            t.bn.lam[j] = hb ? K::mu0 * til : 0.0;
+            t.bn.lam[4 + j] = hb ? K::mu0 * tiu : 0.0;
         }
         if (e == 0) {
             const double z4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -314,9 +338,9 @@ struct Wave2 : Algebra {
                 Con q;
                 con_cached(t, j, q, o);
                 rg[j] += q.lam_u - q.lam_l;
-                viol = viol || (has_bound(t, j) && (fabs(q.rd_l) > c.res_d_max || fabs(q.rd_u) > c.res_d_max ||
-                                                    fabs(fabs(q.rm_l) - c.tau_min) > c.res_m_max ||
-                                                    fabs(fabs(q.rm_u) - c.tau_min) > c.res_m_max));
+                viol = viol || (has_bound(t, j) && (fabs(q.rd_l) > K::res_d_max || fabs(q.rd_u) > K::res_d_max ||
+                                                    fabs(fabs(q.rm_l) - K::tau_min) > K::res_m_max ||
+                                                    fabs(fabs(q.rm_u) - K::tau_min) > K::res_m_max));
                 ps += q.rm_l;
                 ps += q.rm_u;
             }
@@ -335,7 +359,7 @@ struct Wave2 : Algebra {
             }
             if (t.act && !t.is0) { pg = amax(pg, rg[2]); pg = amax(pg, rg[3]); pg = amax(pg, rg[4]); }
         }
-        open = x.gany(pg > c.res_g_max || pb > c.res_b_max || viol);
+        open = x.gany(pg > K::res_g_max || pb > K::res_b_max || viol);
         double ns[1] = {ps};
         x.rsum(ns);
         musum = ns[0];
@@ -378,12 +402,12 @@ struct Wave2 : Algebra {
         const double S02 = P.p00 * a + P.p10 * b + P.p20;
         const double S12 = P.p10 * a + P.p11 * b + P.p21;
         const double S22 = P.p20 * a + P.p21 * b + P.p22;
-        const double Hxx00 = (c.wg[2] + c.reg_prim) + GamX + P.p00;
+        const double Hxx00 = c.wgr[2] + GamX + P.p00;
         const double Hxx10 = P.p10;
-        const double Hxx11 = (c.wg[3] + c.reg_prim) + GamY + P.p11;
+        const double Hxx11 = c.wgr[3] + GamY + P.p11;
         const double Hxx20 = a * P.p00 + b * P.p10 + P.p20;
         const double Hxx21 = a * P.p10 + b * P.p11 + P.p21;
-        const double Hxx22 = (c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22);
+        const double Hxx22 = c.wgr[4] + (a * S02 + b * S12 + S22);
         Sym3 Po;
         Po.p00 = Hxx00 + (g.M00 * g.K00 + g.M10 * g.K10);
         Po.p10 = Hxx10 + (g.M01 * g.K00 + g.M11 * g.K10);
@@ -395,8 +419,8 @@ struct Wave2 : Algebra {
     }
     __device__ __forceinline__ Sym3 terminal_P() const {
         Sym3 P;
-        P.p00 = c.we[0] + c.reg_prim; P.p10 = 0.0; P.p11 = c.we[1] + c.reg_prim;
-        P.p20 = 0.0; P.p21 = 0.0; P.p22 = c.we[2] + c.reg_prim;
+        P.p00 = c.wer[0]; P.p10 = 0.0; P.p11 = c.wer[1];
+        P.p20 = 0.0; P.p21 = 0.0; P.p22 = c.wer[2];
         return P;
     }
     __device__ __forceinline__ static Sym3 zero_P() {
@@ -580,7 +604,7 @@ struct Wave2 : Algebra {
         if (t.mid) {
             const AB8& ab = t.ab;
             r.e = 1.0; r.a = ab.a; r.b = ab.b;
-            const double r0 = rcp((c.wg[0] + c.reg_prim) + Gam[0]), r1 = rcp((c.wg[1] + c.reg_prim) + Gam[1]);
+            const double r0 = rcp(c.wgr[0] + Gam[0]), r1 = rcp(c.wgr[1] + Gam[1]);
             const double b00 = ab.B00 * r0, b10 = ab.B10 * r0, b20 = ab.B20 * r0;
             const double b01 = ab.B01 * r1, b11 = ab.B11 * r1, b21 = ab.B21 * r1;
             r.C[0] = b00 * ab.B00 + b01 * ab.B01;
@@ -589,12 +613,12 @@ struct Wave2 : Algebra {
             r.C[3] = b20 * ab.B00 + b21 * ab.B01;
             r.C[4] = b20 * ab.B10 + b21 * ab.B11;
             r.C[5] = b20 * ab.B20 + b21 * ab.B21;
-            r.j0 = (c.wg[2] + c.reg_prim) + Gam[2]; r.j1 = (c.wg[3] + c.reg_prim) + Gam[3]; r.j2 = c.wg[4] + c.reg_prim;
+            r.j0 = c.wgr[2] + Gam[2]; r.j1 = c.wgr[3] + Gam[3]; r.j2 = c.wgr[4];
         } else {   // terminal stage (0, 0, Q_N); stages beyond N get the same finite element
             r.e = 0.0; r.a = 0.0; r.b = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) r.C[i] = 0.0;
-            r.j0 = c.we[0] + c.reg_prim; r.j1 = c.we[1] + c.reg_prim; r.j2 = c.we[2] + c.reg_prim;
+            r.j0 = c.wer[0]; r.j1 = c.wer[1]; r.j2 = c.wer[2];
         }
         return r;
     }
@@ -980,9 +1004,9 @@ struct Wave2 : Algebra {
         x.rmax(am);
         x.rsum(as);
         o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
-        o.lin_itref = FINAL ? x.gany(!(lin_g < c.itref_tol_g)) : false;
-        o.lin_lq = FINAL ? x.gany(!(lin_g < c.lq_tol)) : false;
-        o.lin_scan = (FINAL && US) ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
+        o.lin_itref = FINAL ? x.gany(!(lin_g < K::itref_tol_g)) : false;
+        o.lin_lq = FINAL ? x.gany(!(lin_g < K::lq_tol)) : false;
+        o.lin_scan = (FINAL && US) ? x.gany(!(lin_g < K::scan_tol_lin)) : false;
         o.redo_centering = false;
         o.accepted = false;
         if (FINAL) {
@@ -1012,13 +1036,13 @@ struct Wave2 : Algebra {
                         con_correct(q, mode, dza[j], sigma_mu * bf(t, j));
                         Step sp;
                         con_step(q, dl[e][j], sp);
-                        const double aj = a_upd * bf(t, j), lmin = c.lam_min * bf(t, j);
+                        const double aj = a_upd * bf(t, j), lmin = K::lam_min * bf(t, j);
                         double ll = t.bn.lam[j] + aj * sp.dl_l, lu = t.bn.lam[4 + j] + aj * sp.dl_u;
                         double tl = t.bn.t[j] + aj * sp.dt_l, tu = t.bn.t[4 + j] + aj * sp.dt_u;
                         if (ll < lmin) ll = lmin;
                         if (lu < lmin) lu = lmin;
-                        if (tl < c.t_min) tl = c.t_min;
-                        if (tu < c.t_min) tu = c.t_min;
+                        if (tl < K::t_min) tl = K::t_min;
+                        if (tu < K::t_min) tu = K::t_min;
                         t.bn.lam[j] = ll; t.bn.lam[4 + j] = lu; t.bn.t[j] = tl; t.bn.t[4 + j] = tu;
                         t.ti[j] = rcp(tl); t.ti[4 + j] = rcp(tu);
                     }
@@ -1033,7 +1057,7 @@ struct Wave2 : Algebra {
     }
 
     // ---- the RTI step (Wave::begin / cont / iterate) ----
-    __device__ __forceinline__ double nc_inv() const { return 1.0 / (4 + 8 * (c.N - 1)); }
+    __device__ __forceinline__ double nc_inv() const { return c.nc_inv; }
     __device__ __forceinline__ void begin(State& st) {
         bu(st.musum, st.open);
         st.mu = st.musum * nc_inv();
@@ -1042,7 +1066,7 @@ struct Wave2 : Algebra {
         st.diag = 0;
     }
     __device__ __forceinline__ bool cont(const State& st) const {
-        return st.kk < c.iter_max && st.alpha > c.alpha_min && st.open;
+        return st.kk < c.iter_max && st.alpha > K::alpha_min && st.open;
     }
     // The search direction of one IPM iteration (OCP_QP_IPM_DELTA_STEP) and, if it is accepted,
     // the variable update.  US: with the parallel scans; the stationarity residual of the linear
@@ -1059,7 +1083,7 @@ struct Wave2 : Algebra {
         const double tmp = mu_aff0 / st.mu;
         const double sigma = tmp * tmp * tmp;
         double sigma_mu = sigma * st.mu;
-        if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+        if (!(sigma_mu > K::tau_min)) sigma_mu = K::tau_min;
         // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
         int mode = 1;
 #pragma nounroll
