@@ -2,9 +2,10 @@
 //
 // Two execution models, both FP64 VALU only — the 2x2 / 3x3 stage blocks
 // are not dense contractions, so no MFMA (BASELINE.json north_star):
-//   WAVE (default)  k_wave: one OCP per wavefront (or per 16/32 lanes, or per 128-thread
-//                   workgroup for N >= 64), lane = stage, IPM workspace in registers, Riccati
-//                   recursion and substitutions as parallel scans — rti_wave.hpp;
+//   WAVE (default)  k_wave2: lane = two consecutive stages, 64 / GW OCPs per wavefront (two at
+//                   N = 50), IPM workspace in registers + LDS, Riccati recursion and substitutions
+//                   as parallel scans — rti_wave2.hpp; k_wave: one stage per lane (N <= 15, full
+//                   SQP, cross-check model WAVE1) — rti_wave.hpp;
 //   LANE            k_phase / k_compact: one OCP per lane, workspace slab in HBM, phased solve
 //                   with straggler compaction — rti_core.hpp.
 // This file adds the batch I/O kernels, the full-SQP head (k_nlp_res), the device closed loop
@@ -31,6 +32,8 @@ using namespace mpc;
 // Batches up to this size go through pinned host memory that the kernel reads and writes
 // directly (no H2D / D2H copies): the batch = 1 control-loop path
 #define MPC_ZEROCOPY_MAX 64
+// wavefronts the chip runs at once at one wavefront per SIMD (256 CUs x 4 SIMDs)
+#define MPC_SIMD_SLOTS 1024
 
 // ------------------------------------------------------------------------------------
 // kernels
@@ -90,10 +93,6 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
 // cross-lane policy of this thread (rti_wave.hpp): registers/DPP for one wavefront, LDS for the
 // two-wavefront workgroup
 template <class X> __device__ __forceinline__ X make_policy(int) { return X(); }
-template <> __device__ __forceinline__ XBlock make_policy<XBlock>(int t) {
-    __shared__ double xb_lds[2 * MPC_XB_MAXN * MPC_XB_LANES];
-    return XBlock(xb_lds, t);
-}
 
 // Batch I/O of k_wave in the C-ABI's AoS layouts (device pointers; x0, yref, yref_e and u0 are
 // required, status / qp_iter may be null): inputs are read straight from the caller's arrays
@@ -342,37 +341,50 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         }
         return;
     }
-    // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update ----
-    double pin[2][3], lamn[2][8], res[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const bool midl = on[e] && 2 * k + e < N;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) pin[e][q] = midl ? ck[e][C_PI + q] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lamn[e][q] = midl ? lk[e][q] : 0.0;
-    }
+    // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update.
+    //      The iterate (x, u, pi, lam) is NOT carried in registers across the QP: every SQP iteration
+    //      reads it from the capsule and an accepted QP writes its solution back (32 doubles per
+    //      lane that would otherwise be live through the whole interior-point loop).  A failed QP
+    //      writes nothing, so the capsule keeps the last accepted iterate. ----
+    double res[4] = {0.0, 0.0, 0.0, 0.0};
     bool running = inst;
     int sqp_it = 0, qp_it = 0, diag = 0;
     status = 2;   // MAXITER unless a residual check passes
     for (;;) {
         if (running && sqp_it >= sqp_max_iter) running = false;   // MAXITER: no check after the last QP
-        if (running) {
-            double xn[2][3];
+        if (!w.x.any(running)) break;
+        // Every lane linearises and cold-starts, whether its OCP still runs or not (a finished
+        // group works on its final iterate and writes nothing): the solver state is then
+        // overwritten on every path around this loop, i.e. dead during the linearisation, instead
+        // of being carried through it in registers on behalf of lanes that will never use it.
+        {
+            double pin[2][3], lamn[2][8], xn[2][3], rr[4];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) w.linearize(e, xi[e], ui[e], xn[e]);
-            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, res);
-            if (res[0] < c.nlp_tol && res[1] < c.nlp_tol && res[2] < c.nlp_tol && res[3] < c.nlp_tol) {
-                status = 0;
-                running = false;
+            for (int e = 0; e < 2; ++e) {
+                const bool midl = on[e] && 2 * k + e < N;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xi[e][q] = on[e] ? ck[e][C_X + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ui[e][q] = midl ? ck[e][C_U + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pin[e][q] = midl ? ck[e][C_PI + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lamn[e][q] = midl ? lk[e][q] : 0.0;
+                w.linearize(e, xi[e], ui[e], xn[e]);
+            }
+            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, rr);
+            if (running) {
+                res[0] = rr[0]; res[1] = rr[1]; res[2] = rr[2]; res[3] = rr[3];
+                if (rr[0] < c.nlp_tol && rr[1] < c.nlp_tol && rr[2] < c.nlp_tol && rr[3] < c.nlp_tol) {
+                    status = 0;
+                    running = false;
+                }
             }
         }
         if (!w.x.any(running)) break;
-        if (running) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) w.cold_start(e, xi[e], ui[e], x0b);
-            w.begin(s);
-        }
+        for (int e = 0; e < 2; ++e) w.cold_start(e, xi[e], ui[e], x0b);
+        w.begin(s);
         for (;;) {
             const bool go = running && w.cont(s);
             if (!w.x.any(go)) break;
@@ -388,14 +400,20 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
             diag |= s.diag;
             ++sqp_it;
             if (hs == 0 || hs == 1) {
-                w.get_pi(pin);
+                double pio[2][3];
+                w.get_pi(pio);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    ui[e][0] = w.s[e].z[0]; ui[e][1] = w.s[e].z[1];
+                    if (!on[e]) continue;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) xi[e][q] = w.s[e].z[2 + q];
+                    for (int q = 0; q < 3; ++q) ck[e][C_X + q] = w.s[e].z[2 + q];
+                    if (2 * k + e < N) {
+                        ck[e][C_U + 0] = w.s[e].z[0]; ck[e][C_U + 1] = w.s[e].z[1];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) lamn[e][q] = W::has_bound(w.s[e], q & 3) ? w.s[e].bn.lam[q] : 0.0;
+                        for (int q = 0; q < 3; ++q) ck[e][C_PI + q] = pio[e][q];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) lk[e][q] = W::has_bound(w.s[e], q & 3) ? w.s[e].bn.lam[q] : 0.0;
+                    }
                 }
             } else {
                 status = 4;
@@ -409,20 +427,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
         if (io.status) io.status[i] = status;
         if (io.qp_iter) io.qp_iter[i] = qp_it;
-        io.u0[2 * i] = ui[0][0]; io.u0[2 * i + 1] = ui[0][1];
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        if (!on[e]) continue;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) ck[e][C_X + q] = xi[e][q];
-        if (2 * k + e < N) {
-            ck[e][C_U + 0] = ui[e][0]; ck[e][C_U + 1] = ui[e][1];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) ck[e][C_PI + q] = pin[e][q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) lk[e][q] = lamn[e][q];
-        }
+        io.u0[2 * i] = ck[0][C_U + 0]; io.u0[2 * i + 1] = ck[0][C_U + 1];
     }
 }
 
@@ -1034,22 +1039,28 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
     do {                                                                                                                  \
         const int per = 64 / GW_;                                                                                         \
         const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
-        if (sqp) hipLaunchKernelGGL((k_wave2<GW_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);             \
-        else if (seq) hipLaunchKernelGGL((k_wave2<GW_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+        if (seq) hipLaunchKernelGGL((k_wave2<GW_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);           \
         else hipLaunchKernelGGL((k_wave2<GW_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                \
     } while (0)
-    if (one_stage_per_lane) {
+    if (N + 1 > 64) {
+        // 64 <= N <= 127: two stages per lane, one OCP per wavefront
+        const dim3 grd(n), blk(64);
+        if (sqp) hipLaunchKernelGGL((k_wave2<64, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
+        else MPC_LAUNCH_WAVE2(64);
+    } else if (one_stage_per_lane || sqp || N + 1 <= 16 || n / (N + 1 <= 32 ? 2 : 1) <= 2 * MPC_SIMD_SLOTS) {
+        // One stage per lane: N + 1 <= 16 fills a 16-lane group as it is (four OCPs per wavefront
+        // either way); full SQP keeps one OCP per wavefront where it can — OCPs that share a
+        // wavefront wait for each other, and SQP iteration counts spread from 1 to 100; and small
+        // batches (the batch = 1 control loop up to two rounds of wavefronts over the chip's 1024
+        // SIMDs) are latency-bound: a wavefront that carries half as many stages per lane finishes
+        // an IPM iteration in 60 % of the time.
         if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
         else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
-        else if (N + 1 <= 64) MPC_LAUNCH_WAVE(XWave<64>);
-        else MPC_LAUNCH_WAVE(XBlock);
+        else MPC_LAUNCH_WAVE(XWave<64>);
     } else {
-        // two stages per lane as soon as that does not leave more lanes idle: N + 1 <= 16 fills a
-        // 16-lane group with one stage per lane (four OCPs per wavefront either way)
-        if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
-        else if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
-        else if (N + 1 <= 64) MPC_LAUNCH_WAVE2(32);
-        else MPC_LAUNCH_WAVE2(64);
+        // SQP_RTI: two stages per lane, two (N + 1 <= 64) or four (N + 1 <= 32) OCPs per wavefront
+        if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
+        else MPC_LAUNCH_WAVE2(32);
     }
 #undef MPC_LAUNCH_WAVE
 #undef MPC_LAUNCH_WAVE2

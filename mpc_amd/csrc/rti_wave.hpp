@@ -20,8 +20,8 @@
 // The per-stage arithmetic is rti_core.hpp's Algebra (same formulas, same order as the
 // lane-per-OCP kernel); the scans and the wave-wide sums re-associate, which moves the results
 // at the 1e-13 level — the same class of deviation as kernel vs oracle.
-// Cross-lane communication goes through a policy (XWave: DPP / ds_bpermute inside one
-// wavefront; XBlock: LDS exchange across the two wavefronts of a 128-thread workgroup).
+// Cross-lane communication goes through a policy (XWave<GW>: DPP / ds_bpermute inside one
+// wavefront, GW lanes per OCP).  Horizons beyond 63 use two stages per lane (rti_wave2.hpp).
 #pragma once
 #include "rti_core.hpp"
 
@@ -177,56 +177,6 @@ struct XWave {
         const int g = (int)(threadIdx.x & 63) / GW;
         return ((b >> (g * GW)) & (~0ull >> (64 - GW))) != 0ull;
     }
-};
-
-// XBlock: one OCP per 128-thread workgroup (two wavefronts, lane = stage for N + 1 <= 128).
-// Values cross the wavefront boundary through LDS: a batch of n values is written to one of two
-// slots, one barrier, neighbours read; alternating slots make the single barrier sufficient (a
-// wavefront can be at most one exchange ahead of the other).
-#define MPC_XB_LANES 128
-#define MPC_XB_MAXN 21
-struct XBlock {
-    static constexpr int LANES = MPC_XB_LANES;
-    static constexpr int THREADS = MPC_XB_LANES;
-    static constexpr int PER_BLOCK = 1;
-    static constexpr bool MCACHE = false;   // (7 levels x 128 lanes would halve the blocks per CU)
-    static constexpr int MC_LEVELS = 0;
-    double* lds;        // [2][MPC_XB_MAXN][128]
-    int t;              // threadIdx.x
-    mutable int slot;
-    __device__ __forceinline__ XBlock(double* lds_, int t_) : lds(lds_), t(t_), slot(0) {}
-    template <int n> __device__ __forceinline__ void shift(double (&v)[n], int delta) const {
-        double* b = lds + slot * (MPC_XB_MAXN * MPC_XB_LANES);
-        slot ^= 1;
-#pragma unroll
-        for (int i = 0; i < n; ++i) b[i * MPC_XB_LANES + t] = v[i];
-        __syncthreads();
-        const int src = t + delta;
-        if (src >= 0 && src < MPC_XB_LANES) {
-#pragma unroll
-            for (int i = 0; i < n; ++i) v[i] = b[i * MPC_XB_LANES + src];
-        }
-    }
-    template <int n> __device__ __forceinline__ void next(double (&v)[n]) const { shift(v, 1); }
-    template <int n> __device__ __forceinline__ void prev(double (&v)[n]) const { shift(v, -1); }
-    template <int n> __device__ __forceinline__ void down(double (&v)[n], int d) const { shift(v, d); }
-    template <int n> __device__ __forceinline__ void up(double (&v)[n], int d) const { shift(v, -d); }
-    template <int n, class Op> __device__ __forceinline__ void reduce(double (&v)[n], Op op) const {
-        double* b = lds + slot * (MPC_XB_MAXN * MPC_XB_LANES);
-        slot ^= 1;
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            v[i] = group_reduce<64>(v[i], op);
-            if ((t & 63) == 0) b[i * MPC_XB_LANES + (t >> 6)] = v[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < n; ++i) v[i] = op(b[i * MPC_XB_LANES], b[i * MPC_XB_LANES + 1]);
-    }
-    template <int n> __device__ __forceinline__ void rmax(double (&v)[n]) const { reduce(v, OpMax()); }
-    template <int n> __device__ __forceinline__ void rsum(double (&v)[n]) const { reduce(v, OpSum()); }
-    __device__ __forceinline__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
-    __device__ __forceinline__ bool gany(bool p) const { return __syncthreads_or(p) != 0; }
 };
 
 template <class X, bool SCAN>

@@ -19,10 +19,6 @@
 #pragma once
 #include "rti_wave.hpp"
 
-#ifndef MPC_CACHE0_COND
-#define MPC_CACHE0_COND (GW < 64)
-#endif
-
 namespace mpc {
 
 template <int GW, bool SCAN>
@@ -64,9 +60,10 @@ struct Wave2 : Algebra {
     // corrector).  Every lane only reads what it wrote itself: no barriers.  Slots of 2 doubles
     // behind the product cache: stage e: 4e..4e+3 = yref[0..4], cv[0..2]; 8+2e, 9+2e = dza[0..3];
     // 12..14 = pi of both stages.
-    // LDS budget: 40 KB per wavefront keeps four wavefronts (one per SIMD) on a CU.  GW = 64 has
-    // six product levels: its level 0 (Psi itself) is recomputed by every scan instead of cached.
-    static constexpr bool CACHE0 = MPC_CACHE0_COND;
+    // LDS budget: 40 KB per wavefront keeps four wavefronts (one per SIMD) on a CU.  Level 0 of
+    // the products (Psi itself) is recomputed by every scan instead of cached: 27 multiply-adds
+    // against 5 LDS reads, measured 3.4 % faster at GW = 32 and needed for the budget at GW = 64.
+    static constexpr bool CACHE0 = false;
     static constexpr int MC_SLOTS = (X::MC_LEVELS - (CACHE0 ? 0 : 1)) * MPC_MC_PAIRS;
     static constexpr int PK0 = MC_SLOTS > 25 ? MC_SLOTS : 25;   // (the cache area also parks 25 slots during the Riccati scan)
     static constexpr int LDS_SLOTS = PK0 + 15;
@@ -372,11 +369,12 @@ struct Wave2 : Algebra {
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // (no has_bound selects: entries without a bound carry lam = 0, t = 1, so Gamma and
+                //  gamma are exact zeros)
                 Con q;
                 con_cached(s[e], j, q, o);
-                const bool hb = has_bound(s[e], j);
-                Gam[e][j] = hb ? con_Gamma_o(q, o) : 0.0;
-                gam[e][j] = hb ? con_gamma(q) : 0.0;
+                Gam[e][j] = con_Gamma_o(q, o);
+                gam[e][j] = con_gamma(q);
             }
     }
     // US: use the parallel scans (compile-time: the sequential fallback of an iteration is a
