@@ -210,19 +210,26 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
 
 /* Execution model of the solve kernels (no counterpart in the reference; results agree to
- * rounding, ~1e-13, across models).  AUTO = WAVE when it applies, else LANE.
- *   LANE     one OCP per lane, IPM workspace in HBM (allocated on the first solve that uses it);
- *   WAVE     one OCP per wavefront (lane = stage), workspace in registers, Riccati recursion
- *            and the two substitutions as parallel scans (64 <= N uses a 128-thread
- *            workgroup per OCP);
- *   WAVE_SEQ same mapping with sequential recursions (cross-check of the scans).
- * The environment
- * variable MPC_MODEL=lane|wave|waveseq sets the default of handles left on AUTO. */
+ * rounding, ~1e-13, across models).  Leave it on AUTO; the others exist for cross-checks.
+ *   AUTO / WAVE  the wave model, kernel chosen by horizon, mode and batch size: lane = stage(s) of
+ *            one OCP, IPM workspace in registers and LDS, Riccati recursion and the two
+ *            substitutions as parallel scans.  Two stages per lane (two OCPs per wavefront at
+ *            N = 50, four at N <= 31, one at 64 <= N <= 127) for SQP_RTI batches larger than four
+ *            rounds of wavefronts over the chip; one stage per lane for small batches (latency),
+ *            N <= 15 and full SQP with N <= 63;
+ *   WAVE1    one stage per lane wherever it applies (N <= 63);   WAVE2: two stages per lane
+ *            wherever it applies (N >= 16, SQP_RTI), whatever the batch size;
+ *   WAVE_SEQ / WAVE2_SEQ  the same mappings with sequential recursions instead of the scans;
+ *   LANE     one OCP per lane, IPM workspace in HBM (allocated on the first solve that uses it).
+ * The environment variable MPC_MODEL=lane|wave|wave1|wave2|waveseq sets the default of handles
+ * left on AUTO. */
 #define MPC_MODEL_AUTO 0
 #define MPC_MODEL_LANE 1
 #define MPC_MODEL_WAVE 2
 #define MPC_MODEL_WAVE_SEQ 3
 #define MPC_MODEL_WAVE1 4
+#define MPC_MODEL_WAVE2 5
+#define MPC_MODEL_WAVE2_SEQ 6
 int mpc_batch_set_model(mpc_batch_t* h, int model);
 
 /* Introspection used by bench/tests: kernel time of the last solve in ms

@@ -221,7 +221,7 @@ class BatchSolver:
         self._check(lib().mpc_batch_get_diag(self._h, B, _pi(d)), "mpc_batch_get_diag")
         return d
 
-    MODELS = {"auto": 0, "lane": 1, "wave": 2, "waveseq": 3, "wave1": 4}
+    MODELS = {"auto": 0, "lane": 1, "wave": 2, "waveseq": 3, "wave1": 4, "wave2": 5, "wave2seq": 6}
 
     def set_model(self, model):
         """Execution model of the solve kernels: 'auto', 'lane', 'wave', 'waveseq' (include/mpc_batch.h)."""

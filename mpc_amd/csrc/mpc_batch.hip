@@ -946,6 +946,7 @@ static int pick_model(const mpc_batch* h) {
         else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
         else if (strcmp(model_env, "wave1") == 0) model = MPC_MODEL_WAVE1;
+        else if (strcmp(model_env, "wave2") == 0) model = MPC_MODEL_WAVE2;
     }
     if (model == MPC_MODEL_AUTO) model = MPC_MODEL_WAVE;
     return model;
@@ -1024,7 +1025,7 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
 // (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
 static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
-                        bool one_stage_per_lane = false) {
+                        bool one_stage_per_lane = false, bool two_stages_per_lane = false) {
     const int N = c.N;
     const bool sqp = sqp_max_iter > 1;
     seq = seq && !sqp;
@@ -1047,11 +1048,12 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
         const dim3 grd(n), blk(64);
         if (sqp) hipLaunchKernelGGL((k_wave2<64, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
         else MPC_LAUNCH_WAVE2(64);
-    } else if (one_stage_per_lane || sqp || N + 1 <= 16 || n / (N + 1 <= 32 ? 2 : 1) <= 2 * MPC_SIMD_SLOTS) {
+    } else if (one_stage_per_lane || sqp || N + 1 <= 16 ||
+               (!two_stages_per_lane && n / (N + 1 <= 32 ? 2 : 1) <= 4 * MPC_SIMD_SLOTS)) {
         // One stage per lane: N + 1 <= 16 fills a 16-lane group as it is (four OCPs per wavefront
         // either way); full SQP keeps one OCP per wavefront where it can — OCPs that share a
         // wavefront wait for each other, and SQP iteration counts spread from 1 to 100; and small
-        // batches (the batch = 1 control loop up to two rounds of wavefronts over the chip's 1024
+        // batches (the batch = 1 control loop up to four rounds of wavefronts over the chip's 1024
         // SIMDs) are latency-bound: a wavefront that carries half as many stages per lane finishes
         // an IPM iteration in 60 % of the time.
         if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
@@ -1068,7 +1070,8 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
 
 static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
     HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ, st, model == MPC_MODEL_WAVE1);
+    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ || model == MPC_MODEL_WAVE2_SEQ, st,
+                model == MPC_MODEL_WAVE1 || model == MPC_MODEL_WAVE_SEQ, model == MPC_MODEL_WAVE2 || model == MPC_MODEL_WAVE2_SEQ);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1598,7 +1601,7 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag) {
 }
 
 int mpc_batch_set_model(mpc_batch_t* h, int model) {
-    if (!h || model < MPC_MODEL_AUTO || model > MPC_MODEL_WAVE1) return -1;
+    if (!h || model < MPC_MODEL_AUTO || model > MPC_MODEL_WAVE2_SEQ) return -1;
     h->model = model;
     return 0;
 }

@@ -352,11 +352,11 @@ def test_device_closed_loop_matches_per_vehicle_optimizers(oracle):
 
 @pytest.mark.parametrize("name,B", [("mobile_robot", 2500), ("park", 600), ("mobile_robot_25", 300)])
 def test_execution_models_agree(oracle, name, B):
-    """The three execution models (include/mpc_batch.h MPC_MODEL_*) on the same inputs, cold tick
+    """The execution models (include/mpc_batch.h MPC_MODEL_*) on the same inputs, cold tick
     + 2 warm ticks: each within the parity bar of the oracle, same status and iteration counts."""
     sp, wl = workload.make(name, B)
     solvers = {}
-    for model in ("lane", "wave", "waveseq"):
+    for model in ("lane", "wave", "waveseq", "wave1", "wave2", "wave2seq"):
         solvers[model] = capi.BatchSolver(sp, B)
         solvers[model].set_model(model)
     xo = uo = None
@@ -373,15 +373,17 @@ def test_execution_models_agree(oracle, name, B):
         s.close()
 
 
-@pytest.mark.parametrize("N", [1, 2, 7, 15, 16, 31, 32, 63])
-def test_wave_model_group_widths(oracle, N):
-    """Horizons at the edges of the 16-/32-/64-lane groups of the wave kernel (several OCPs per
-    wavefront for N <= 31), ragged batch."""
+@pytest.mark.parametrize("model,N", [("wave1", n) for n in (1, 2, 7, 15, 16, 31, 32, 63)] +
+                         [("wave2", n) for n in (16, 17, 30, 31, 32, 33, 49, 50, 62, 63, 64, 65, 100, 126, 127)])
+def test_wave_model_group_widths(oracle, model, N):
+    """Horizons at the edges of the 16-/32-/64-lane groups of the wave kernels, one and two stages
+    per lane (several OCPs per wavefront for the narrower groups; odd and even N put the terminal
+    stage in either slot of the last lane), ragged batch."""
     B = 37
     sp, wl = workload.make("mobile_robot", B, N=N)
     x0, yref, yref_e = wl.tick(0)
     s = capi.BatchSolver(sp, B)
-    s.set_model("wave")
+    s.set_model(model)
     ro = oracle.rti_batch(sp, x0, yref, yref_e)
     rg = s.solve(x0, yref, yref_e)
     xg, ug, _ = s.get(B, want_pi=False)
@@ -496,7 +498,7 @@ def test_active_state_bounds_stress(oracle, name, box):
     x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
     sp = sp.copy(lbx=(-box, -box), ubx=(box, box))
     solvers, drift = {}, {}
-    for model in ("wave", "waveseq", "lane"):
+    for model in ("wave1", "wave2", "waveseq", "wave2seq", "lane"):
         solvers[model] = capi.BatchSolver(sp, B)
         solvers[model].set_model(model)
         drift[model] = capi.BatchSolver(sp, B)
@@ -514,7 +516,7 @@ def test_active_state_bounds_stress(oracle, name, box):
             worst = max(worst, dev)
             assert dev < TOL_HARD, (model, t, dev)
             dg = s.get_diag(B)
-            if model == "wave":
+            if model in ("wave1", "wave2"):
                 fallbacks += int(((dg & 4) != 0).sum())
             else:
                 assert ((dg & 4) == 0).all()
@@ -569,9 +571,9 @@ def test_device_closed_loop_past_the_end_of_the_path(oracle):
 
 
 @pytest.mark.parametrize("N", [64, 80, 127])
-def test_workgroup_variant_of_the_wave_model(oracle, N):
-    """64 <= N <= 127: one OCP per 128-thread workgroup (XBlock policy: LDS exchange across the two
-    wavefronts).  RTI cold + warm tick and a short full-SQP run, against the oracle."""
+def test_long_horizons_of_the_wave_model(oracle, N):
+    """64 <= N <= 127: two stages per lane, one OCP per wavefront (k_wave2<64>), SQP_RTI and full
+    SQP.  RTI cold + warm tick and a short full-SQP run, against the oracle."""
     B = 70
     sp, wl = workload.make("mobile_robot", B, N=N)
     s = capi.BatchSolver(sp, B)
@@ -665,8 +667,9 @@ def test_device_closed_loop_with_shifted_warm_start(oracle):
     solver.close(); solver2.close()
 
 
+@pytest.mark.parametrize("model", ["wave1", "wave2"])
 @pytest.mark.parametrize("N", [50, 25, 15])
-def test_non_finite_inputs_stay_inside_their_instance(N):
+def test_non_finite_inputs_stay_inside_their_instance(N, model):
     """Several OCPs can share a wavefront (N <= 31) and the scans shuffle across lanes without a
     partner guard where one OCP owns the wavefront: an instance fed NaN / Inf must not change a
     single bit of any other instance's result, and must itself come back failed."""
@@ -674,6 +677,7 @@ def test_non_finite_inputs_stay_inside_their_instance(N):
     sp, wl = workload.make("mobile_robot", B, N=N)
     x0, yref, yref_e = wl.tick(0)
     clean = capi.BatchSolver(sp, B)
+    clean.set_model(model)
     rc = clean.solve(x0, yref, yref_e)
     xc, uc, _ = clean.get(B, want_pi=False)
     bad = np.zeros(B, bool); bad[[0, 5, 6, 64, 127, 130, 202]] = True
@@ -682,6 +686,7 @@ def test_non_finite_inputs_stay_inside_their_instance(N):
     x0p[6, 2] = np.inf
     yrefp[[127, 130, 202], N // 2, 0] = np.nan
     dirty = capi.BatchSolver(sp, B)
+    dirty.set_model(model)
     rd = dirty.solve(x0p, yrefp, yref_e)
     xd, ud, _ = dirty.get(B, want_pi=False)
     ok = ~bad
