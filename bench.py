@@ -5,15 +5,16 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one control tick of the whole batch: one mpc_batch_solve_device call (AoS->SoA
-packing, one SQP-RTI step per instance, u0/status/iterate-independent outputs) on inputs that
-are already resident in HBM.  Every rank owns one GPU and 65536 instances (weak scaling: the
-instances are independent, no collective on the data path); value = instances solved by all
-ranks / max-over-ranks wall time.  Tick t tracks a window shifted by t waypoints from the
-previous iterate (the reference's warm start: no shifting of the trajectory,
-src/optimizer.cpp:208-296).
+A "step" is one control tick of the whole batch: one mpc_batch_solve_device call (one SQP-RTI
+step per instance; u0, status and iteration counts out) on inputs that are already resident in
+HBM.  Every rank owns one GPU and 65536 instances (weak scaling: the instances are independent,
+no collective on the data path; mpc_amd/sharding.py carries the barrier and the max-over-ranks
+time); value = instances solved by all ranks / max-over-ranks wall time.  Tick t tracks a window
+shifted by t waypoints from the previous iterate (the reference's warm start: no shifting of the
+trajectory, src/optimizer.cpp:208-296).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,14 +25,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 x 2.4 GHz
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 x 2.4 GHz (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-# HBM bytes of one k_wave launch (65536 x N=50) from the rocprofv3 PMC passes in profiles/r01 (v12):
-# FETCH_SIZE 2.909e5 KiB x 2 (gfx950 correction of the guide) + WRITE_SIZE 3.69e5 KiB
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 0.97e9
-# FP64 flops one k_wave launch (65536 x N=50, warm ticks) EXECUTES, from the SQ counters in
-# profiles/r01/v12_pmc_sq.csv: (2 x 8.58e8 FMA + 5.31e8 MUL + 2.61e8 ADD wave-instructions) x 64 lanes
-MEASURED_FP64_FLOP_PER_LAUNCH = 1.60e11
+# Counter-derived figures of the dominant kernel (HBM bytes moved, FP64 flops executed per launch)
+# come from the rocprofv3 passes committed under profiles/; the summary names the sources it was
+# taken on, and the bench line says `stale: true` when the kernel sources have changed since.
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02", "summary.json")
+KERNEL_SOURCES = ("mpc_amd/csrc/mpc_batch.hip", "mpc_amd/csrc/rti_wave2.hpp", "mpc_amd/csrc/rti_wave.hpp",
+                  "mpc_amd/csrc/rti_core.hpp", "mpc_amd/csrc/consts.hpp", "include/mpc_hpipm_args.h")
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile_summary(B, N):
+    """Per-launch counter figures of the profiled configuration, or None."""
+    try:
+        s = json.load(open(PROFILE_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    if s.get("batch") != B or s.get("horizon") != N:
+        return None
+    s["stale"] = s.get("kernel_source_sha") != kernel_source_sha()
+    return s
 
 
 def algorithmic_bytes_per_solve(N):
@@ -66,45 +87,27 @@ def main():
     ap.add_argument("--variant", default="mobile_robot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal of the multi-rank flow)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    from mpc_amd import sharding
+    rank, local_rank, world = sharding.env_rank()
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch
-    import torch.distributed as dist
     from mpc_amd import capi, workload
 
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The collective backend only carries the barrier and the max-over-ranks time (no
-        # collective on the data path); if RCCL cannot start on this node the measurement falls
-        # back to gloo for those two calls and says so in the JSON line.
-        if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-                dist.barrier()
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: nccl/RCCL unavailable ({e}); using gloo for barrier/all_reduce", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                args.backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    ranks = sharding.connect(args.backend, rank, world, dev, log=lambda m: print(f"[bench] {m}", file=sys.stderr))
 
     B, K, W = args.batch, args.steps, args.warmup
-    sp, wl = workload.make(args.variant, B, first=rank * B)
+    lo, hi = sharding.shard_range(world * B, world, rank)       # this rank's contiguous slice of the global batch
+    sp, wl = workload.make(args.variant, hi - lo, first=lo)
     N = sp.N
     solver = capi.BatchSolver(sp, B, devices=[local_rank])
 
@@ -126,38 +129,21 @@ def main():
         solver.last_kernel_ms()  # synchronises the handle's stream
         torch.cuda.synchronize()
 
-    for t in range(W):
-        step(t)
-    sync()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kernel_ms, phase0_ms = [], []
-    qp_hist = []
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        step(t)
-        # per-step kernel time from HIP events on the launch stream (this waits for the step;
+    kernel_ms, launch_ms = [], []
+
+    def record(_t):
+        # per-step device time from HIP events on the launch stream (this waits for the step;
         # steps are dependent through the warm start anyway)
         kernel_ms.append(solver.last_kernel_ms())
-        phase0_ms.append(solver.last_phase0_ms())
-    sync()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        launch_ms.append(solver.last_phase0_ms())
+
+    elapsed = sharding.timed_steps(step, sync, W, K, ranks, after_step=record)
     qp_iter_last = d_it.cpu().numpy()
     status_last = d_st.cpu().numpy()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    out = None
     if rank == 0:
         total = world * B * K
         value = total / elapsed
-        mean_kernel_ms = float(np.mean(kernel_ms))
-        mean_it = float(qp_iter_last.mean())
         out = {
             "metric": "OCP solves/sec, mobile_robot N=50 SQP-RTI, 65536 instances per GPU",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -166,75 +152,105 @@ def main():
             "config": {"workload": f"{args.variant} N={N} Ts={sp.Ts} SQP-RTI (HPIPM BALANCE, qp_iter_max {sp.qp_iter_max}), "
                                    f"{B} arc-tracking instances per GPU, warm iterate, seed {workload.SEED}",
                        "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (independent shards, no collective)",
-                       "barrier_backend": (("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None)},
-            "mean_qp_iter": mean_it, "max_qp_iter": int(qp_iter_last.max()),
+                       "barrier_backend": ranks.backend},
+            "mean_qp_iter": float(qp_iter_last.mean()), "max_qp_iter": int(qp_iter_last.max()),
             "failed_instances": int((status_last != 0).sum()),
-            "kernel_ms_per_step": mean_kernel_ms,
+            "kernel_ms_per_step": float(np.mean(kernel_ms)),
+            "handle_device_bytes": solver.device_bytes(),
         }
-        # ---- roofline of the dominant kernel: k_wave (one OCP per wavefront, workspace in registers) ----
+        # ---- roofline of the dominant kernel: the wave-model solve launch.  The binding roof is the
+        #      FP64 vector unit (~60 flop per byte of batch I/O, no MFMA); the HBM
+        #      figures of the same launch ride along. ----
         f0, f1, trig = flops_model(N)
-        flops_step = float((f0 + f1 * qp_iter_last).sum())
-        bytes_step = algorithmic_bytes_per_solve(N) * B
-        p0_ms = float(np.mean(phase0_ms))
-        ach_gbs = bytes_step / (p0_ms * 1e-3) / 1e9
-        traffic = MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (B == 65536 and N == 50) else None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_wave<64,scan>", "launch_ms": p0_ms,
-                           "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                           "traffic": traffic,
-                           "note": "achieved = ALGORITHMIC bytes (batch I/O: x0, yref, yref_e in; u0, status, qp_iter out = "
-                                   f"{algorithmic_bytes_per_solve(N)} B/solve) / live HIP-event duration of the launch; the kernel "
-                                   "keeps the IPM workspace in registers and is bound by FP64 VALU issue, not by HBM: see roofline_fp64"}
-        if traffic:
-            out["roofline"]["hbm_traffic_rate"] = traffic / (p0_ms * 1e-3) / 1e9  # GB/s actually moved
-        ach_tf = flops_step / (p0_ms * 1e-3) / 1e12
-        out["roofline_fp64"] = {"bound": "fp64_vector", "kernel": "k_wave<64,scan>", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
-                                "flops_per_solve": flops_step / B, "trig_calls_per_solve": trig,
-                                "model": f"{f0:.0f} + {f1:.0f}*qp_iter (op count of the dense SEQUENTIAL restatement = algorithmic "
-                                         "flops; the parallel scans execute more, see executed_*) over the k_wave launch"}
-        if traffic:   # same configuration as the PMC passes
-            ex_tf = MEASURED_FP64_FLOP_PER_LAUNCH / (p0_ms * 1e-3) / 1e12
-            out["roofline_fp64"]["executed_achieved"] = ex_tf
-            out["roofline_fp64"]["executed_frac"] = ex_tf / FP64_VECTOR_PEAK_TFLOPS
-            out["roofline_fp64"]["executed_note"] = ("FP64 flops the launch executes by the SQ instruction counters (rocprofv3 --pmc, "
-                                                     "profiles/r01/v12_pmc_sq.csv; all 64 lanes counted, idle stages and scan overhead included)")
-        # ---- batch=1 latency (second half of the metric) ----
+        flops_launch = float((f0 + f1 * qp_iter_last).sum())
+        bytes_launch = float(algorithmic_bytes_per_solve(N) * B)
+        l_ms = float(np.mean(launch_ms))
+        ach_tf = flops_launch / (l_ms * 1e-3) / 1e12
+        ach_gbs = bytes_launch / (l_ms * 1e-3) / 1e9
+        prof = load_profile_summary(B, N)
+        roof = {"bound": "fp64_vector", "kernel": "k_wave2<32,scan,rti>" if 32 < N + 1 <= 64 else "wave-model solve kernel",
+                "launch_ms": l_ms, "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
+                "flops_per_solve": flops_launch / B, "trig_calls_per_solve": trig,
+                "model": f"algorithmic flops = {f0:.0f} + {f1:.0f}*qp_iter per solve (op count of the dense SEQUENTIAL restatement; "
+                         "the parallel scans execute more, see executed_*), summed over the launch, / live HIP-event duration",
+                "traffic": None,
+                "hbm": {"algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N), "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS}}
+        if prof:
+            roof["traffic"] = prof.get("hbm_traffic_bytes_per_launch")
+            if roof["traffic"]:
+                roof["hbm"]["traffic_rate"] = roof["traffic"] / (l_ms * 1e-3) / 1e9          # GB/s actually moved
+                roof["hbm"]["traffic_over_algorithmic"] = roof["traffic"] / bytes_launch
+            ex = prof.get("executed_fp64_flop_per_launch")
+            if ex:
+                roof["executed_achieved"] = ex / (l_ms * 1e-3) / 1e12
+                roof["executed_frac"] = roof["executed_achieved"] / FP64_VECTOR_PEAK_TFLOPS
+            roof["counters_from"] = {"file": os.path.relpath(PROFILE_SUMMARY, ROOT), "commit": prof.get("commit"),
+                                     "kernel_source_sha": prof.get("kernel_source_sha"), "stale": prof["stale"]}
+        out["roofline"] = roof
+        # ---- batch=1 latency (second half of the metric; BASELINE.md §3: >= 1000 ticks) ----
         if not args.no_latency:
             sp1, wl1 = workload.make(args.variant, 1)
             s1 = capi.BatchSolver(sp1, 1, devices=[local_rank])
             lat, klat = [], []
-            for t in range(60):
-                x0, yref, yref_e = wl1.tick(t)
+            for t in range(1010):
+                x0, yref, yref_e = wl1.tick(t % 64)
                 ta = time.perf_counter()
                 s1.solve(x0, yref, yref_e)
                 lat.append(1e3 * (time.perf_counter() - ta))
                 klat.append(s1.last_kernel_ms())
             s1.close()
             out["latency_b1_ms"] = {"p50": float(np.percentile(lat[10:], 50)), "p99": float(np.percentile(lat[10:], 99)),
-                                    "kernel_p50": float(np.percentile(klat[10:], 50)),
+                                    "kernel_p50": float(np.percentile(klat[10:], 50)), "ticks": 1000,
                                     "note": "mpc_batch_solve with host pointers in/out, end to end (inputs staged in pinned host memory the kernel reads directly)"}
-        # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample ----
+        # ---- the same tick through the host-pointer entry point (PCIe-inclusive; never `value`) ----
+        if not args.no_e2e:
+            e2e = {}
+            hs = capi.BatchSolver(sp, B, devices=[local_rank])
+            for kind in ("pageable", "pinned"):
+                ms = []
+                for t in range(4):
+                    arrs = [np.ascontiguousarray(a) for a in wl.tick(t)]
+                    if kind == "pinned":
+                        keep = [torch.from_numpy(a).pin_memory() for a in arrs]
+                        arrs = [k.numpy() for k in keep]
+                    ta = time.perf_counter()
+                    hs.solve(*arrs)
+                    ms.append(1e3 * (time.perf_counter() - ta))
+                e2e[kind] = float(np.median(ms[1:]))
+                hs.reset()
+            hs.close()
+            out["e2e_host_ms_per_step"] = dict(e2e, note="mpc_batch_solve on host numpy arrays: H2D of x0/yref/yref_e, the solve, D2H of u0/status/qp_iter; "
+                                               "median of 3 warm ticks (u0 returned into pageable memory in both cases)")
+        # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample, on rank 0 only ----
         if not args.no_cpu_baseline:
             from tests import oracle_lib   # the only use of the oracle in this file: the thing timed as the CPU baseline
-            nthr = min(oracle_lib.lib().oracle_max_threads(), 16)
-            ns = min(B, 8192)
-            xo = uo = None
-            tcpu = 0.0
-            for t in range(4):
-                x0, yref, yref_e = wl.tick(t)
-                ta = time.perf_counter()
-                r = oracle_lib.rti_batch(sp, x0[:ns], yref[:ns], yref_e[:ns], xo, uo, nthreads=nthr)
-                if t > 0:
-                    tcpu += time.perf_counter() - ta
-                xo, uo = r["xtraj"], r["utraj"]
-            out["cpu_baseline"] = {"value": 3 * ns / tcpu, "unit": "solves/s", "cores": nthr, "kind": "port",
-                                   "sample": f"first {ns} instances of the same workload, ticks 1-3 (warm), "
-                                             f"dense C++ oracle -O2 + OpenMP; acados itself is unavailable offline"}
+            nthr = oracle_lib.lib().oracle_max_threads()   # the box's CPU share (OMP_NUM_THREADS), not the whole machine
+            ns = min(B, 32768)
+
+            def timed(threads, n, nt):
+                xo = uo = None
+                tcpu = 0.0
+                for t in range(nt + 1):
+                    x0, yref, yref_e = wl.tick(t)
+                    ta = time.perf_counter()
+                    r = oracle_lib.rti_batch(sp, x0[:n], yref[:n], yref_e[:n], xo, uo, nthreads=threads)
+                    if t > 0:
+                        tcpu += time.perf_counter() - ta
+                    xo, uo = r["xtraj"], r["utraj"]
+                return nt * n / tcpu
+
+            v_all = timed(nthr, ns, 3)
+            v_one = timed(1, min(ns, 2048), 3)
+            out["cpu_baseline"] = {"value": v_all, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                   "host_cores": os.cpu_count(), "single_thread_value": v_one,
+                                   "sample": f"first {ns} instances of the same workload, ticks 1-3 (warm), dense C++ oracle -O2 + OpenMP on the "
+                                             f"{nthr} OpenMP threads this job may use (os.cpu_count() reports {os.cpu_count()}); single thread: "
+                                             f"first {min(ns, 2048)} instances; acados itself is unavailable offline"}
         print(json.dumps(out), flush=True)
     solver.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -63,3 +63,68 @@ def gather_rows(local, total, device="cpu"):
     outs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return np.concatenate([outs[r][: hi - lo].cpu().numpy() for r, (lo, hi) in enumerate(sizes)], axis=0)
+
+
+class Ranks:
+    """The distributed context of one benchmark / driver process: rank, world size, the
+    torch.distributed group (None for a single process) and the device the scalar collectives
+    run on.  The data path never uses it — only `barrier` and `max_over_ranks`."""
+
+    def __init__(self, rank=0, world=1, dist=None, backend=None, device="cpu"):
+        self.rank, self.world, self.dist, self.backend, self.device = rank, world, dist, backend, device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, value):
+        return max_over_ranks(value, self.device) if self.dist is not None else float(value)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def connect(backend, rank, world, device=None, log=None):
+    """init() with the fallback the bench needs: if RCCL ("nccl") cannot start on this node the
+    two scalar collectives go over gloo instead (and the result says so)."""
+    if world <= 1:
+        return Ranks()
+    import torch.distributed as dist
+    if backend == "nccl":
+        try:
+            init("nccl", rank, world, device)
+            dist.barrier()
+            return Ranks(rank, world, dist, "rccl", device)
+        except Exception as e:  # noqa: BLE001
+            if log:
+                log(f"rank {rank}: nccl/RCCL unavailable ({e}); using gloo for barrier/all_reduce")
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            backend = "gloo"
+    init(backend, rank, world)
+    return Ranks(rank, world, dist, backend, "cpu")
+
+
+def timed_steps(step, sync, warmup, steps, ranks, after_step=None):
+    """The timing protocol of the bench contract: `warmup` untimed steps, then exactly `steps`
+    steps bracketed by (device sync + barrier) on both sides; returns the MAX over ranks of the
+    wall time in seconds.  step(t) enqueues step t (t counts from 0 through the warm-up),
+    sync() waits for this rank's device, after_step(t) may record per-step data."""
+    import time
+    for t in range(warmup):
+        step(t)
+    sync()
+    ranks.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for t in range(warmup, warmup + steps):
+        step(t)
+        if after_step:
+            after_step(t)
+    sync()
+    ranks.barrier()
+    return ranks.max(time.perf_counter() - t0)

@@ -22,21 +22,28 @@ def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
     from mpc_amd import sharding, workload
     from tests import hostcore_lib
-    sharding.init("gloo", rank, world)
+    # the same calls bench.py makes: connect (nccl would fall back to gloo; here gloo directly),
+    # a contiguous shard per rank, timed_steps (warm-up, barrier-bracketed timed region, MAX over ranks)
+    ranks = sharding.connect("gloo", rank, world)
+    assert ranks.world == world and ranks.backend == "gloo"
     lo, hi = sharding.shard_range(total, world, rank)
     sp, wl = workload.make("mobile_robot_18", hi - lo, first=lo)
-    x0, yref, yref_e = wl.tick(0)
-    dist.barrier()
-    r = hostcore_lib.rti_batch(sp, x0, yref, yref_e)
-    dist.barrier()
-    t = sharding.max_over_ranks(1.0 + rank)
-    u0_all = sharding.gather_rows(r["u0"], total)
+    state = {"x": None, "u": None, "r": None, "seen": []}
+
+    def step(t):
+        x0, yref, yref_e = wl.tick(t)
+        state["r"] = hostcore_lib.rti_batch(sp, x0, yref, yref_e, state["x"], state["u"])
+        state["x"], state["u"] = state["r"]["xtraj"], state["r"]["utraj"]
+
+    elapsed = sharding.timed_steps(step, lambda: None, 1, 2, ranks, after_step=state["seen"].append)
+    assert state["seen"] == [1, 2] and elapsed > 0.0
+    t = ranks.max(1.0 + rank)
+    u0_all = sharding.gather_rows(state["r"]["u0"], total)
     np.save(os.path.join(out_dir, f"u0_rank{rank}.npy"), u0_all)
-    np.save(os.path.join(out_dir, f"t_rank{rank}.npy"), np.array([t]))
-    dist.destroy_process_group()
+    np.save(os.path.join(out_dir, f"t_rank{rank}.npy"), np.array([t, elapsed]))
+    ranks.close()
 
 
 @pytest.mark.timeout(300)
@@ -48,9 +55,16 @@ def test_two_rank_sharded_solve_equals_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
     sp, wl = workload.make("mobile_robot_18", total)
-    x0, yref, yref_e = wl.tick(0)
-    ref = hostcore_lib.rti_batch(sp, x0, yref, yref_e)
+    xo = uo = None
+    for t in range(3):   # warm-up tick + two timed ticks, as in the workers
+        x0, yref, yref_e = wl.tick(t)
+        ref = hostcore_lib.rti_batch(sp, x0, yref, yref_e, xo, uo)
+        xo, uo = ref["xtraj"], ref["utraj"]
+    times = []
     for r in range(world):
         got = np.load(tmp_path / f"u0_rank{r}.npy")
         assert got.shape == (total, 2) and np.array_equal(got, ref["u0"])
-        assert np.load(tmp_path / f"t_rank{r}.npy")[0] == float(world)
+        tt = np.load(tmp_path / f"t_rank{r}.npy")
+        assert tt[0] == float(world)
+        times.append(tt[1])
+    assert times[0] == times[1]          # the timed region's wall time is the MAX over ranks on every rank

@@ -70,5 +70,17 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
 if "SQ_WAVE_CYCLES" in c:
     wc = c["SQ_WAVE_CYCLES"]
     summary["shares_of_wave_cycles"] = {k: c[k] / wc for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS") if k in c}
+# what bench.py needs to tie the counters to a build (it recomputes the hash at run time)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    summary["kernel_source_sha"] = bench.kernel_source_sha()
+except Exception as e:  # noqa: BLE001
+    summary["kernel_source_sha"] = None
+hc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".head_commit")
+summary["commit"] = open(hc).read().strip() if os.path.exists(hc) else None
+summary["batch"] = 65536
+summary["horizon"] = 50
+summary["command"] = "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-latency --no-e2e (one rocprofv3 run per counter group, tools/prof.sh)"
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernel_stats_top"}, indent=1))
