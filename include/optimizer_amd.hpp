@@ -11,15 +11,20 @@
 // are members, so several Optimizer objects can coexist; the path files are looked up in
 // `paths_dir` (constructor argument / $MPC_PATHS_DIR) instead of a path derived from __FILE__.
 //
-// Vector types: with Eigen available (the reference's build) the Eigen types are used, so
-// `controller.cpp` compiles unchanged against this header; without Eigen a minimal stand-in with
-// the members this class needs (operator(), operator[], rows(), cols(), head<>) is used.
+// Vector types: with Eigen available (the reference's build) they are Eigen::Vector3d / VectorXd /
+// MatrixXd themselves (column-major, so `Eigen::MatrixXd* p = &mpc.left_turn_states` and
+// `mpc.state_refs = Eigen::Map<...>(...).transpose()` of src/controller.cpp:210-213,1515 keep their
+// types); without Eigen a minimal stand-in with the members this class needs is used.
+// Every `mpc.<member>` that src/controller.cpp names exists here with the reference's signature;
+// tests/cpp/optimizer_surface_main.cpp calls each of them (stand-in types: this image has neither
+// Eigen nor ROS, so a build of controller.cpp itself against this header has NOT been made).
 #pragma once
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
 #include <limits>
 #include <sstream>
 #include <stdexcept>
@@ -40,7 +45,7 @@ namespace mpc_amd {
 #ifdef MPC_HAVE_EIGEN
 using Vector3d = Eigen::Vector3d;
 using VectorXd = Eigen::VectorXd;
-using MatrixXd = Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+using MatrixXd = Eigen::MatrixXd;
 #else
 struct Vector3d {
     double v[3] = {0, 0, 0};
@@ -62,7 +67,9 @@ struct VectorXd {
     double& operator()(int i) { return v[i]; }
     const double& operator()(int i) const { return v[i]; }
     int size() const { return (int)v.size(); }
+    int rows() const { return (int)v.size(); }
     double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
 };
 struct MatrixXd {   // row-major
     int r = 0, c = 0;
@@ -105,6 +112,10 @@ class Optimizer {
             const std::string sfx = path_name + std::to_string(v_ref_int) + ".txt";
             state_refs = loadTxt(dir + "/state_refs" + sfx);
             input_refs = loadTxt(dir + "/input_refs" + sfx);
+            const MatrixXd a = loadTxt(dir + "/wp_attributes" + sfx);   // src/optimizer.cpp:146
+            state_attributes = VectorXd((int)a.rows());
+            for (int i = 0; i < (int)a.rows(); ++i) state_attributes(i) = a(i, 0);
+            normals = loadTxt(dir + "/wp_normals" + sfx);               // :159
             set_path_loaded();
         }
         if (this->v_ref > 0.3) this->v_ref = 0.35;   // src/optimizer.cpp:174
@@ -113,8 +124,11 @@ class Optimizer {
     Optimizer(const Optimizer&) = delete;
     Optimizer& operator=(const Optimizer&) = delete;
 
-    // path given directly instead of files
+    // path given directly instead of files (what src/controller.cpp:210-213 does by assignment)
     void set_path(const MatrixXd& s, const MatrixXd& u) { state_refs = s; input_refs = u; set_path_loaded(); }
+    void set_path(const MatrixXd& s, const MatrixXd& u, const VectorXd& attributes, const MatrixXd& wp_normals) {
+        state_refs = s; input_refs = u; state_attributes = attributes; normals = wp_normals; set_path_loaded();
+    }
 
     int run() {   // src/optimizer.cpp:177-206
         int hsy = 0;
@@ -130,19 +144,27 @@ class Optimizer {
     }
 
     int update_and_solve(Vector3d& i_current_state, bool safety_check = true, int mode = -1) {   // :208-319
-        (void)mode;   // the turn/straight tables of the reference are empty unless loaded
+        // mode selects the waypoint table (:215-226); a table that was never filled (the reference
+        // leaves all three empty, :147-149, and would index out of range) falls back to state_refs
+        if (mode == -1) state_refs_ptr = &state_refs;
+        else if (mode == 0) state_refs_ptr = &left_turn_states;
+        else if (mode == 1) state_refs_ptr = &straight_states;
+        else if (mode == 2) state_refs_ptr = &right_turn_states;
+        else { std::cerr << "Invalid mode, proceed with default mode" << std::endl; state_refs_ptr = &state_refs; }
+        if (state_refs_ptr->rows() == 0) state_refs_ptr = &state_refs;
+        const MatrixXd& refs = *state_refs_ptr;
         find_next_waypoint(target_waypoint_index, i_current_state, safety_check);
-        const int rows = state_refs.rows();
-        const int idx = target_waypoint_index < rows ? target_waypoint_index : rows - 1;
+        const int rows = (int)refs.rows();
+        const int idx = target_waypoint_index < (int)state_refs.rows() ? target_waypoint_index : (int)state_refs.rows() - 1;
         std::vector<double> yref((size_t)N * 5, 0.0);
-        double yref_e[3] = {state_refs(target_waypoint_index, 0), state_refs(target_waypoint_index, 1),
-                            state_refs(target_waypoint_index, 2)};   // terminal ref = first waypoint (:244-251)
+        double yref_e[3] = {refs(target_waypoint_index, 0), refs(target_waypoint_index, 1),
+                            refs(target_waypoint_index, 2)};   // terminal ref = first waypoint (:244-251)
         for (int j = 0; j < N; ++j) {
             double* y = &yref[(size_t)j * 5];
             if (target_waypoint_index + j >= rows) {
-                for (int q = 0; q < 3; ++q) y[q] = state_refs(rows - 1, q);
+                for (int q = 0; q < 3; ++q) y[q] = refs(rows - 1, q);
             } else {
-                for (int q = 0; q < 3; ++q) y[q] = state_refs(idx + j, q);
+                for (int q = 0; q < 3; ++q) y[q] = refs(idx + j, q);
                 y[3] = input_refs(idx + j, 0);
             }
             y[4] = 0.0;   // "set steer rate to 0" (:271)
@@ -157,7 +179,7 @@ class Optimizer {
             return 1;
         }
         u_current[0] = u0[0]; u_current[1] = u0[1];
-        iter++;
+        if (debug) record_tick(i_current_state);   // :300-317
         return 0;
     }
 
@@ -197,7 +219,7 @@ class Optimizer {
         int target;
         if (count_ >= 8) { target = closest_waypoint_index + lookahead_; count_ = 0; }
         else { target = target_waypoint_index + 1; count_++; }
-        output_target = std::min(target, (int)state_refs.rows() - 1);
+        output_target = std::min(target, (int)state_refs_ptr->rows() - 1);
         last_waypoint_index = output_target;
         return 1;
     }
@@ -212,7 +234,49 @@ class Optimizer {
         state[0] = x; state[1] = y; state[2] = yaw;
         return 1;
     }
-    int update_current_states(double x, double y, double yaw) { return update_current_states(x, y, yaw, x_current); }
+    int update_current_states(double x, double y, double yaw, bool safety_check = true) {
+        return update_current_states(x, y, yaw, x_current, safety_check);
+    }
+    int initialize_current_states(double x, double y, double yaw) {   // include/optimizer.hpp:62-64
+        return update_current_states(x, y, yaw, x_current, false);
+    }
+
+    // ---- waypoint attributes (include/optimizer.hpp:94-105) ----
+    enum ATTRIBUTE {
+        NORMAL, CROSSWALK, INTERSECTION, ONEWAY, HIGHWAYLEFT, HIGHWAYRIGHT, ROUNDABOUT, STOPLINE, DOTTED, DOTTED_CROSSWALK
+    };
+    // an attribute + 100 marks the same kind of waypoint where signs / lines cannot be detected
+    bool attribute_cmp(int idx, int attr) const {
+        if (idx < 0 || idx >= (int)state_attributes.size()) return false;
+        const double a = state_attributes(idx);
+        return a == attr || a == attr + 100;
+    }
+    bool is_not_detectable(int idx) const {
+        return state_attributes(idx) >= 100 || attribute_cmp(idx, DOTTED_CROSSWALK) || attribute_cmp(idx, INTERSECTION) ||
+               attribute_cmp(idx, ROUNDABOUT);
+    }
+    int get_current_attribute() const { return (int)state_attributes(target_waypoint_index); }   // :440-442
+    // the N waypoints from the target on (:443-445); like the reference's block(), the caller keeps
+    // target_waypoint_index + N inside the table
+    void get_current_waypoints(MatrixXd& output) const {
+        if (target_waypoint_index + N > (int)state_refs.rows()) throw std::out_of_range("get_current_waypoints: window past the end of state_refs");
+        if ((int)output.rows() != N || (int)output.cols() != 3) output = MatrixXd(N, 3);
+        for (int j = 0; j < N; ++j) for (int q = 0; q < 3; ++q) output(j, q) = state_refs(target_waypoint_index + j, q);
+    }
+    // lateral shift of the waypoints [start_index, end_index) along their normals, ramped in and out
+    // over int(density / 8) waypoints (:335-372); to the left unless shift_right
+    void change_lane(int start_index, int end_index, bool shift_right = false, double shift_distance = 0.36 - 0.1) {
+        if (shift_right) shift_distance *= -1;
+        const int ramp_length = static_cast<int>(density * 0.125);
+        const int ramp_up_end = start_index + ramp_length, ramp_down_start = end_index - ramp_length;
+        for (int i = start_index; i < end_index; i++) {
+            double shift = shift_distance;
+            if (i < ramp_up_end) shift = shift_distance * (static_cast<double>(i - start_index + 1) / ramp_length);
+            else if (i >= ramp_down_start) shift = shift_distance * (static_cast<double>(end_index - i) / ramp_length);
+            state_refs(i, 0) += normals(i, 0) * shift;
+            state_refs(i, 1) += normals(i, 1) * shift;
+        }
+    }
 
     int reset_solver() { return mpc_batch_reset(mpc_, nullptr); }   // include/optimizer.hpp:446-456
 
@@ -240,6 +304,20 @@ class Optimizer {
         while (nearest - yaw < -M_PI) nearest += 2 * M_PI;
         return nearest;
     }
+    static int NearestDirectionIndex(double yaw) {   // :268-294: 0 east, 1 north, 2 west, 3 south
+        while (yaw > 2 * M_PI) yaw -= 2 * M_PI;
+        while (yaw < 0) yaw += 2 * M_PI;
+        int best = 0;
+        double best_d = std::abs(yaw);
+        for (int i = 1; i < 5; ++i) {
+            const double d = std::abs(yaw - i * (M_PI / 2));
+            if (d < best_d) { best_d = d; best = i; }
+        }
+        return best == 4 ? 0 : best;
+    }
+    // the reference's signatures (Eigen::VectorXd&, include/optimizer.hpp:167,191)
+    void set_up_park(const VectorXd& xs) { set_up_park(xs.data()); }
+    int update_and_solve_park(const VectorXd& xs, double thresh_sq = 0.0025) { return update_and_solve_park(xs.data(), thresh_sq); }
     void set_up_park(const double xs[5]) {
         mpc_batch_reset(mpc_park_, nullptr);
         for (int q = 0; q < 5; ++q) park_xs_[q] = xs[q];
@@ -261,7 +339,43 @@ class Optimizer {
         status = st;
         if (status != 0) return 1;
         u_current[0] = u0[0]; u_current[1] = u0[1];
+        if (debug) record_tick(x_current);   // :223-236
         return 0;
+    }
+
+    // ---- statistics of the recorded run (src/optimizer.cpp:472-518) ----
+    // [mean speed, mean steer, mean |d speed|, mean |d steer|, mean |x err|, mean |y err|, mean |yaw err|]
+    // over the `iter` recorded ticks (the reference averages the errors over its whole zero-padded
+    // 2*num_waypoints buffers; the padding is left out here).  Files are written only when
+    // `results_dir` is set (the reference writes next to its sources).
+    VectorXd computeStats(int hsy = 0) {
+        (void)hsy;
+        const int n = iter;
+        VectorXd stats(7);
+        for (int q = 0; q < 7; ++q) stats(q) = 0.0;
+        if (n == 0) return stats;
+        for (int k = 0; k < n; ++k) {
+            stats(0) += simU_[2 * k]; stats(1) += simU_[2 * k + 1];
+            if (k) { stats(2) += std::abs(simU_[2 * k] - simU_[2 * k - 2]); stats(3) += std::abs(simU_[2 * k + 1] - simU_[2 * k - 1]); }
+            stats(4) += std::abs(err_[3 * k]); stats(5) += std::abs(err_[3 * k + 1]);
+            stats(6) += std::abs(std::atan2(std::sin(err_[3 * k + 2]), std::cos(err_[3 * k + 2])));
+        }
+        stats(0) /= n; stats(1) /= n; stats(4) /= n; stats(5) /= n; stats(6) /= n;
+        if (n > 1) { stats(2) /= n - 1; stats(3) /= n - 1; }
+        simX = MatrixXd(n, 3); simU = MatrixXd(n, 2);
+        for (int k = 0; k < n; ++k) {
+            for (int q = 0; q < 3; ++q) simX(k, q) = simX_[3 * k + q];
+            for (int q = 0; q < 2; ++q) simU(k, q) = simU_[2 * k + q];
+        }
+        if (!results_dir.empty()) {
+            saveToFile(simX, results_dir + "/simX.txt");
+            saveToFile(simU, results_dir + "/simU.txt");
+            MatrixXd st(7, 1);
+            for (int q = 0; q < 7; ++q) st(q, 0) = stats(q);
+            saveToFile(st, results_dir + "/stats.txt");
+            saveToFile(state_refs, results_dir + "/state_refs.txt");
+        }
+        return stats;
     }
 
     // ---- text I/O (src/optimizer.cpp:532-577) ----
@@ -302,11 +416,25 @@ class Optimizer {
     Vector3d x_current, x_real, frame1, frame2, x_current_transformed;
     double u_current[2] = {0.0, 0.0};
     bool shift_warm_start = false;   // extension (mpc_batch_shift); false = the reference's behaviour
-    MatrixXd state_refs, input_refs;
+    MatrixXd state_refs, input_refs, normals, left_turn_states, right_turn_states, straight_states;
+    MatrixXd* state_refs_ptr = &state_refs;
+    VectorXd state_attributes;
+    MatrixXd simX, simU;        // filled by computeStats() from the recorded ticks
+    std::string results_dir;    // where computeStats() writes its files; empty = nowhere
     static constexpr double rdb_circumference = 3.95;
 
   private:
-    void set_path_loaded() { num_waypoints = state_refs.rows(); }
+    void set_path_loaded() { num_waypoints = (int)state_refs.rows(); state_refs_ptr = &state_refs; }
+    // per-tick record behind computeStats (the reference's simX / simU / *_errors, which it sizes
+    // 2*num_waypoints and overruns on longer runs; these grow)
+    void record_tick(const Vector3d& state) {
+        const int t = std::min(target_waypoint_index, (int)state_refs.rows() - 1);
+        simU_.push_back(u_current[0]); simU_.push_back(u_current[1]);
+        for (int q = 0; q < 3; ++q) simX_.push_back(state[q]);
+        for (int q = 0; q < 3; ++q) err_.push_back(t >= 0 ? state_refs(t, q) - x_real[q] : 0.0);
+        iter++;
+    }
+    std::vector<double> simX_, simU_, err_;
     mpc_batch_t* mpc_ = nullptr;
     mpc_batch_t* mpc_park_ = nullptr;
     int limit_ = -1, lookahead_ = 1, count_ = 0;   // function-statics of the reference, per object

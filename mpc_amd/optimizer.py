@@ -110,10 +110,10 @@ class Optimizer:
         self.last_waypoint_index = 0
         self.closest_waypoint_index = 0
         self.iter = 0
-        n = self.num_waypoints * 2
-        self.simX = np.zeros((n, 3)); self.simU = np.zeros((n, 2))
-        self.x_errors = np.zeros(n); self.y_errors = np.zeros(n); self.yaw_errors = np.zeros(n)
-        self.time_record = np.zeros(n)
+        # per-tick record behind computeStats (the reference's simX / simU / *_errors buffers, which
+        # it sizes 2*num_waypoints and overruns on longer runs; these grow)
+        self._simX, self._simU, self._err = [], [], []
+        self.results_dir = None
         if self.v_ref > 0.3:
             self.v_ref = 0.35  # src/optimizer.cpp:174
         # per-instance versions of the function-statics of find_next_waypoint / find_closest_waypoint
@@ -217,15 +217,103 @@ class Optimizer:
         if self.status != 0:
             return 1
         self.u_current = out["u0"][0].copy()
-        if self.debug and self.iter < self.simU.shape[0]:
-            self.simU[self.iter] = self.u_current
-            self.simX[self.iter] = i_current_state
-            t = min(self.target_waypoint_index, self.state_refs.shape[0] - 1)
-            self.x_errors[self.iter] = self.state_refs[t, 0] - self.x_real[0]
-            self.y_errors[self.iter] = self.state_refs[t, 1] - self.x_real[1]
-            self.yaw_errors[self.iter] = self.state_refs[t, 2] - self.x_real[2]
-            self.iter += 1
+        if self.debug:
+            self._record_tick(i_current_state)
         return 0
+
+    def _record_tick(self, state):
+        """src/optimizer.cpp:300-317 / include/optimizer.hpp:223-236."""
+        t = min(self.target_waypoint_index, self.state_refs.shape[0] - 1)
+        self._simU.append(np.array(self.u_current, np.float64))
+        self._simX.append(np.array(state, np.float64))
+        self._err.append(self.state_refs[t, :3] - self.x_real if t >= 0 else np.zeros(3))
+        self.iter += 1
+
+    @property
+    def simX(self):
+        return np.array(self._simX).reshape(-1, 3)
+
+    @property
+    def simU(self):
+        return np.array(self._simU).reshape(-1, 2)
+
+    def computeStats(self, hsy=0):
+        """src/optimizer.cpp:472-518: [mean speed, mean steer, mean |d speed|, mean |d steer|,
+        mean |x err|, mean |y err|, mean |yaw err|] over the recorded ticks (the reference averages
+        the errors over its zero-padded buffers; the padding is left out).  Files only when
+        `results_dir` is set."""
+        n = self.iter
+        stats = np.zeros(7)
+        if n == 0:
+            return stats
+        U, E = self.simU, np.array(self._err).reshape(-1, 3)
+        stats[0], stats[1] = U[:, 0].mean(), U[:, 1].mean()
+        if n > 1:
+            dU = np.abs(np.diff(U, axis=0))
+            stats[2], stats[3] = dU[:, 0].mean(), dU[:, 1].mean()
+        stats[4], stats[5] = np.abs(E[:, 0]).mean(), np.abs(E[:, 1]).mean()
+        stats[6] = np.abs(np.arctan2(np.sin(E[:, 2]), np.cos(E[:, 2]))).mean()
+        if self.results_dir:
+            np.savetxt(f"{self.results_dir}/simX.txt", self.simX)
+            np.savetxt(f"{self.results_dir}/simU.txt", U)
+            np.savetxt(f"{self.results_dir}/stats.txt", stats)
+            np.savetxt(f"{self.results_dir}/state_refs.txt", self.state_refs)
+        return stats
+
+    # ------------------------------------------------------------------ waypoint attributes
+    (NORMAL, CROSSWALK, INTERSECTION, ONEWAY, HIGHWAYLEFT, HIGHWAYRIGHT, ROUNDABOUT, STOPLINE, DOTTED,
+     DOTTED_CROSSWALK) = range(10)   # enum ATTRIBUTE, include/optimizer.hpp:94-96
+
+    def attribute_cmp(self, idx, attr):
+        """include/optimizer.hpp:97-102: attribute, or the same + 100 (not detectable there)."""
+        if idx < 0 or idx >= self.state_attributes.shape[0]:
+            return False
+        a = self.state_attributes[idx]
+        return bool(a == attr or a == attr + 100)
+
+    def is_not_detectable(self, idx):
+        """include/optimizer.hpp:103-105."""
+        return bool(self.state_attributes[idx] >= 100 or self.attribute_cmp(idx, self.DOTTED_CROSSWALK)
+                    or self.attribute_cmp(idx, self.INTERSECTION) or self.attribute_cmp(idx, self.ROUNDABOUT))
+
+    def get_current_attribute(self):
+        return int(self.state_attributes[self.target_waypoint_index])
+
+    def get_current_waypoints(self):
+        """include/optimizer.hpp:443-445."""
+        t = self.target_waypoint_index
+        if t + self.N > self.state_refs.shape[0]:
+            raise IndexError("get_current_waypoints: window past the end of state_refs")
+        return self.state_refs[t:t + self.N, :3].copy()
+
+    def change_lane(self, start_index, end_index, shift_right=False, shift_distance=0.36 - 0.1):
+        """include/optimizer.hpp:335-372: shift [start, end) along the normals, ramped over
+        int(density / 8) waypoints at both ends."""
+        if shift_right:
+            shift_distance *= -1
+        ramp = int(self.density * 0.125)
+        up_end, down_start = start_index + ramp, end_index - ramp
+        for i in range(start_index, end_index):
+            shift = shift_distance
+            if i < up_end:
+                shift = shift_distance * ((i - start_index + 1) / ramp)
+            elif i >= down_start:
+                shift = shift_distance * ((end_index - i) / ramp)
+            self.state_refs[i, :2] += np.asarray(self.normals)[i, :2] * shift
+
+    @staticmethod
+    def NearestDirectionIndex(yaw):
+        """include/optimizer.hpp:268-294: 0 east, 1 north, 2 west, 3 south."""
+        while yaw > 2 * math.pi:
+            yaw -= 2 * math.pi
+        while yaw < 0:
+            yaw += 2 * math.pi
+        best, best_d = 0, abs(yaw)
+        for i in range(1, 5):
+            d = abs(yaw - i * (math.pi / 2))
+            if d < best_d:
+                best, best_d = i, d
+        return 0 if best == 4 else best
 
     def integrate_next_states(self):
         """src/optimizer.cpp:321-341 (H16): one ERK4 step of the variant's Tsim."""
@@ -330,6 +418,8 @@ class Optimizer:
         if self.status != 0:
             return 1
         self.u_current = out["u0"][0].copy()
+        if self.debug:
+            self._record_tick(self.x_current)
         return 0
 
     def close(self):

@@ -433,6 +433,106 @@ def test_cpp_optimizer_shim():
     o.close()
 
 
+def test_cpp_optimizer_surface():
+    """Every `mpc.<member>` that the reference's src/controller.cpp names, called through the C++
+    drop-in (tests/cpp/optimizer_surface_main.cpp) and, in the same order, on the Python mirror
+    driving the same library: attributes, direction indices, published window, lane change, ticks
+    with update_current_states, a manoeuvre on a turn table (mode 0 / 2, empty table, bad mode),
+    parking with the VectorXd signatures, computeStats."""
+    import math
+    import os
+    import subprocess
+    from mpc_amd import variants
+    from mpc_amd.optimizer import Optimizer, load_txt
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "_build", "optimizer_surface_main")
+    assert os.path.exists(exe), "build it with `make -C tests/cpp` (done by __graft_entry__.build())"
+    sf = os.path.join(here, "golden", "state_refs_path150_head.txt")
+    uf = os.path.join(here, "golden", "input_refs_path150_head.txt")
+    out = subprocess.run([exe, sf, uf], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Invalid mode" in out.stderr
+    rows = [l.split() for l in out.stdout.strip().splitlines()]
+    pos = [0]
+
+    def take(tag):
+        r = rows[pos[0]]
+        pos[0] += 1
+        assert r[0] == tag, (r, tag)
+        return [float(v) for v in r[1:]]
+
+    def close(got, want, tol=1e-12):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64).ravel()
+        assert got.shape == want.shape and np.abs(got - want).max() <= tol, (got, want)
+
+    s, u = load_txt(sf), load_txt(uf)
+    M = s.shape[0]
+    i = np.arange(M)
+    attrs = ((i // 7) % 10 + np.where((i // 31) % 2 == 1, 100, 0)).astype(np.float64)
+    nrm = np.stack([-np.sin(s[:, 2]), np.cos(s[:, 2])], axis=1)
+    o = Optimizer(0.1, 40, 0.5, state_refs=s.copy(), input_refs=u, state_attributes=attrs, normals=nrm)
+    o.initialize_current_states(s[0, 0] + 0.01, s[0, 1] - 0.02, s[0, 2] + 4 * math.pi)
+    close(take("init"), o.x_current)
+    o.target_waypoint_index = o.find_closest_waypoint(0, M - 1)
+    close(take("reset"), [o.reset_solver()])
+    close(take("dims"), [o.N, o.target_waypoint_index, o.last_waypoint_index, o.T, o.density, o.num_waypoints, u.shape[0]])
+    for k in (-1, 0, 13, 14, 21, 35, 44, 63, 70, M - 1, M):
+        close(take("attr"), [k, o.attribute_cmp(k, o.CROSSWALK), o.attribute_cmp(k, o.INTERSECTION),
+                             o.attribute_cmp(k, o.DOTTED_CROSSWALK), o.is_not_detectable(k) if 0 <= k < M else -1])
+    close(take("enum"), list(range(10)))
+    assert (o.NORMAL, o.STOPLINE, o.DOTTED_CROSSWALK) == (0, 7, 9)
+    for yaw in (-7.0, -3.2, -1.5, -0.8, 0.0, 0.7, 0.79, 1.6, 2.4, 3.1, 3.95, 4.7, 5.5, 6.2, 6.3, 13.0):
+        close(take("dir"), [yaw, o.NearestDirectionIndex(yaw), o.NearestDirection(yaw)])
+    w = o.get_current_waypoints()
+    close(take("window"), [w.shape[0], float(np.sum(w * np.array([1.0, 2.0, 3.0]))), o.get_current_attribute()], 1e-9)
+    o.change_lane(20, 70, True, 0.3)
+    o.change_lane(90, 120)
+    for k in (19, 20, 23, 45, 66, 69, 70, 95, 119):
+        close(take("lane"), [k, o.state_refs[k, 0], o.state_refs[k, 1]])
+    assert np.abs(o.state_refs[19] - s[19]).max() == 0 and abs(np.hypot(*(o.state_refs[45, :2] - s[45, :2])) - 0.3) < 1e-12
+    for k in range(30):
+        rc = o.update_and_solve(o.x_current, True)
+        o.integrate_next_states()
+        o.update_current_states(o.x_current[0], o.x_current[1], o.x_current[2] - 2 * math.pi, None, True)
+        close(take("tick"), [rc, o.target_waypoint_index, *o.u_current, *o.x_current])
+    base = o.target_waypoint_index
+    f1 = np.array([o.state_refs[base, 0], o.state_refs[base, 1], o.NearestDirection(o.state_refs[base, 2])])
+    f2 = np.zeros(3)
+    turn = np.stack([o.transform_point(o.state_refs[base + k], f1, f2) for k in range(60)])
+    o.frame1, o.frame2 = f1, f2
+    o.left_turn_states = turn
+    o.right_turn_states = turn.copy()
+    close(take("table"), [60])
+    keep = (o.target_waypoint_index, o.last_waypoint_index)
+    o.target_waypoint_index = o.last_waypoint_index = 0
+    for mode in (0, 2, 1, 7):
+        o.x_current_transformed = o.transform_point(o.x_current, o.frame1, o.frame2)
+        rc = o.update_and_solve(o.x_current_transformed, True, mode)
+        close(take("turn"), [mode, rc, o.target_waypoint_index, *o.u_current])
+        close(take("xt"), o.x_current_transformed)
+        if mode == 2:
+            o.target_waypoint_index, o.last_waypoint_index = keep
+    xs = np.array([0.63, 0.32, 0.0, 0.0, 0.0])
+    o.set_up_park(xs)
+    close(take("frame1"), o.frame1)
+    close(take("frame2"), o.frame2)
+    st, k = 0, 0
+    while True:
+        st = o.update_and_solve_park(xs, 0.1 * 0.1)
+        if st == 2 or k > 200:
+            break
+        o.x_current = o._solver_park.sim_step(o.x_current.reshape(1, 3), o.u_current.reshape(1, 2))[0]
+        k += 1
+    close(take("park"), [st, k])
+    assert st == 2
+    close(take("xt"), o.x_current_transformed)
+    stats = o.computeStats(357)
+    close(take("stats"), [o.iter, *stats], 1e-11)
+    close(take("sim"), [o.simX.shape[0], o.simU.shape[0], o.simX[3, 1], o.simU[3, 0]])
+    assert pos[0] == len(rows)
+    o.close()
+
+
 def test_config1_closed_loop_n18_variant():
     """BASELINE config 1: the `mobile_robot_18` variant (N=40, Ts=0.125, v_ref 0.18) in a single
     closed-loop run, batch = 1, on references produced by mpc_amd/pathgen.py from an S-shaped run;
