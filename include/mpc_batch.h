@@ -194,19 +194,27 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
 int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
 
 /* Per-instance diagnostic bits of the last solve (host pointer diag [B]); 0 on every workload the
- * bench measures.  No counterpart in the reference: they record where this solver's arithmetic
- * left, or would have left, HPIPM's path (deviations).
- *   1  the stationarity residual of the corrector's linear system was not below res_g_max:
- *      HPIPM's corrector iterative refinement (itref_corr_max = 2) applies
- *   2  that residual was not below 1e-5: HPIPM's lq_fact = 1 switch to the LQ factorisation
- *      would have fired (not performed here)
- *   4  wave model: the same residual was not below 1e-8 (absolute, fixed: kScanTolLin in
- *      mpc_amd/csrc/consts.hpp) after an iteration computed with the parallel scans, and the
- *      iteration's direction was recomputed with the sequential recursions inside the kernel.
- *      (A direction whose residual is below 1e-8 is accepted without further checks.) */
+ * bench measures.  No counterpart in the reference: they record where the solve took a path of
+ * its own next to HPIPM's.
+ *   1  REFINED: HPIPM's corrector iterative refinement was PERFORMED in at least one iteration
+ *      (itref_corr_max = 2, acados_solver_mobile_robot.c:670 BALANCE mode): the residual of the
+ *      linearised KKT system at the corrector's direction was not below (res_g_max, res_b_max,
+ *      res_d_max, res_m_max), so the system was solved again for the residual with the same
+ *      factorisation, up to twice, and the step lengths recomputed (wave models)
+ *   2  that residual was above 1e-5: HPIPM's lq_fact = 1 switch to the LQ factorisation may have
+ *      fired in the reference (the test is made on the corrector's direction here, on the affine one
+ *      in HPIPM; the refactorisation itself is not performed, here or in the oracle)
+ *   4  wave models: a direction computed with the parallel scans left the stationarity or the
+ *      dynamics row of the linear system at 1e-8 or more (absolute, fixed: kScanTolLin in
+ *      mpc_amd/csrc/consts.hpp); the instance's QP was solved again from its start by the
+ *      sequential kernel (sequential Riccati recursion + the refinement of bit 1), launched behind
+ *      the scan kernel on the instances it declined.  A scan direction below 1e-8 is taken as is.
+ *   8  lane model only (the cross-check model): the refinement of bit 1 applied and was NOT
+ *      performed */
 #define MPC_DIAG_ITREF 1
 #define MPC_DIAG_LQ 2
 #define MPC_DIAG_SCAN_FALLBACK 4
+#define MPC_DIAG_ITREF_SKIPPED 8
 int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
 
 /* Execution model of the solve kernels (no counterpart in the reference; results agree to

@@ -89,8 +89,9 @@ inline size_t wave_bytes_for(int N) { return (size_t)(N + 1) * MPC_RPS * 64 * si
 inline size_t n_waves_for(size_t capacity) { return (capacity + 63) / 64; }
 inline size_t slab_bytes_for(int N, size_t capacity) { return n_waves_for(capacity) * wave_bytes_for(N); }
 inline size_t cap_doubles_for(int N, size_t capacity) { return n_waves_for(capacity) * 64 * (size_t)(N + 1) * MPC_CAP; }
-inline size_t islab_ints_for(size_t capacity) { return 14 * n_waves_for(capacity) * 64; }
-// the handle's small per-instance arrays: STATUS, QPITER, DIAG, SQPITER, ACTIVE (int), NLPRES [4]
+inline size_t islab_ints_for(size_t capacity) { return 16 * n_waves_for(capacity) * 64; }
+// the handle's small per-instance arrays: STATUS, QPITER, DIAG, SQPITER, ACTIVE (int), NLPRES [4],
+// REDO (64 + S ints)
 inline Mem make_mem(int* islab, size_t capacity, int N) {
     const size_t S = n_waves_for(capacity) * 64;
     Mem m;
@@ -100,6 +101,8 @@ inline Mem make_mem(int* islab, size_t capacity, int N) {
     m.SQPITER = islab + 3 * S; m.ACTIVE = islab + 4 * S;
     m.NLPRES = reinterpret_cast<double*>(islab + 6 * S);   // S is a multiple of 64: 8-byte aligned
     m.cap = nullptr; m.lam = nullptr; m.u0 = nullptr;
+    m.REDO = islab + 14 * S;   // 2 S >= 64 + S ints
+    m.redo_parity = 0;
     return m;
 }
 // element (instance i, stage k, row r) as an index in doubles from the slab start

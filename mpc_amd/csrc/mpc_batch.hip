@@ -123,6 +123,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     // product cache of the scans (rti_wave.hpp build_products): [level][pair][lane] double2
     __shared__ mc_d2 mc_lds[(X::MCACHE && SCAN) ? X::MC_LEVELS * MPC_MC_PAIRS * 64 : 1];
     Wave<X, SCAN> w(c, k, xpol, mc_lds + (l & 63));
+    if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter (Mem::REDO)
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll
@@ -163,6 +164,10 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
             for (int q = 0; q < 3; ++q) xi[q] = w.z[2 + q];
         }
         if (!on) return;
+        if (SCAN && s.declined) {   // nothing is written: the sequential kernel redoes this QP (k_wave2<.., LIST>)
+            if (k == 0) m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+            return;
+        }
         if (k == 0) {
             m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag; m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 #pragma unroll
     for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? lk[q] : 0.0;
     bool running = inst;
+    bool redo = false;
     int sqp_it = 0, qp_it = 0, diag = 0;
     status = 2;   // MAXITER unless a residual check passes
     for (;;) {
@@ -213,6 +219,12 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
             if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
+        if (SCAN && running && s.declined) {
+            // the last accepted iterate goes to the capsule below and the sequential kernel carries
+            // on from there (k_wave2<.., SQP, LIST>), with the count of finished SQP iterations
+            redo = true;
+            running = false;
+        }
         if (running) {
             int hs;
             if (s.kk == c.iter_max) hs = 1;
@@ -235,7 +247,11 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         }
     }
     if (!on) return;
-    if (k == 0) {
+    if (k == 0 && redo) {
+        m.SQPITER[i] = sqp_it;
+        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+    }
+    if (k == 0 && !redo) {
         m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
@@ -257,16 +273,32 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 // The same step with TWO stages per lane (rti_wave2.hpp): lane k of a GW-lane group owns stages 2k
 // and 2k+1, 64 / GW OCPs per wavefront (N = 50: two).  Same I/O as k_wave: the lane reads and
 // writes two consecutive capsule lines (128 B) and two consecutive yref rows (80 B).
-template <int GW, bool SCAN, bool SQP>
+// SCAN: the hot kernel, parallel scans only; an instance whose scan step is declined (rti_wave2.hpp
+// iterate) writes nothing and is appended to m.REDO.  LIST (with SCAN = false): the sequential kernel
+// over the instances listed in m.REDO — sequential recursions plus HPIPM's iterative refinement —
+// launched right behind the hot kernel with the same grid (blocks beyond the list return at once).
+template <int GW, bool SCAN, bool SQP, bool LIST>
 __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
     typedef Wave2<GW, SCAN> W;
+    static_assert(!(SCAN && LIST), "the list kernel is the sequential one");
     constexpr int G = W::PER_BLOCK;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;
-    const size_t i = (size_t)blockIdx.x * G + g;
     const int N = c.N;
-    const bool inst = i < (size_t)B;
-    const size_t ic = inst ? i : (size_t)B - 1;
+    size_t i, ic;
+    bool inst;
+    if (LIST) {
+        const int cnt = m.REDO[m.redo_parity];
+        const int slot0 = (int)blockIdx.x * G;
+        if (slot0 >= cnt) return;
+        inst = slot0 + g < cnt;
+        i = ic = (size_t)m.REDO[MPC_REDO_LIST + (inst ? slot0 + g : slot0)];
+    } else {
+        i = (size_t)blockIdx.x * G + g;
+        inst = i < (size_t)B;
+        ic = inst ? i : (size_t)B - 1;
+        if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter
+    }
     __shared__ mc_d2 mc_lds[W::LDS_SLOTS * 64];   // product cache of the scans + parked per-stage state
     W w(c, k, mc_lds + l);
     double* ck[2];
@@ -317,14 +349,16 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         else hs = 0;
         const bool ok = (hs == 0 || hs == 1);
         status = ok ? 0 : 4;
-        if (inst && k == 0) {
-            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag; m.STATUS[i] = status;
+        const bool redo = SCAN && s.declined;   // nothing is written; the list kernel redoes this QP
+        if (redo && inst && k == 0) m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        if (inst && k == 0 && !redo) {
+            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag | (LIST ? MPC_DIAG_SCAN_FALLBACK : 0); m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
             if (io.qp_iter) io.qp_iter[i] = s.kk;
             // on a QP failure the previous u_0 stays in force
             io.u0[2 * i] = ok ? w.s[0].z[0] : u_prev0; io.u0[2 * i + 1] = ok ? w.s[0].z[1] : u_prev1;
         }
-        if (ok) {
+        if (ok && !redo) {
             double pio[2][3];
             w.get_pi(pio);
 #pragma unroll
@@ -346,9 +380,13 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
     //      reads it from the capsule and an accepted QP writes its solution back (32 doubles per
     //      lane that would otherwise be live through the whole interior-point loop).  A failed QP
     //      writes nothing, so the capsule keeps the last accepted iterate. ----
+    //      A declined scan step (SCAN) ends the instance's loop with the capsule at its last accepted
+    //      iterate and the count of finished SQP iterations in SQPITER: the list kernel carries on
+    //      from exactly there.
     double res[4] = {0.0, 0.0, 0.0, 0.0};
     bool running = inst;
-    int sqp_it = 0, qp_it = 0, diag = 0;
+    bool redo = false;
+    int sqp_it = (LIST && inst) ? m.SQPITER[i] : 0, qp_it = 0, diag = LIST ? MPC_DIAG_SCAN_FALLBACK : 0;
     status = 2;   // MAXITER unless a residual check passes
     for (;;) {
         if (running && sqp_it >= sqp_max_iter) running = false;   // MAXITER: no check after the last QP
@@ -390,6 +428,10 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
             if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
+        if (SCAN && running && s.declined) {
+            redo = true;
+            running = false;
+        }
         if (running) {
             int hs;
             if (s.kk == c.iter_max) hs = 1;
@@ -421,7 +463,11 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
             }
         }
     }
-    if (inst && k == 0) {
+    if (redo && inst && k == 0) {
+        m.SQPITER[i] = sqp_it;
+        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+    }
+    if (inst && k == 0 && !redo) {
         m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
@@ -802,6 +848,7 @@ struct Shard {
     double* capbuf = nullptr;  // Mem::cap
     double* lambuf = nullptr;  // Mem::lam (full-SQP handles only)
     int* islab = nullptr;
+    int redo_parity = 0;   // see Mem::REDO
     double* d_u0 = nullptr;    // [S][2] u_0 of the last solve when the caller passes none
     // lane model only, allocated on its first use (ensure_lane)
     char* slab = nullptr;    // workspace: inputs, iterate rows, IPM workspace
@@ -1024,30 +1071,62 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // The wave-model launch: reads the C-ABI's arrays and the capsules and writes them back.
 // wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
 // (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
-static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
-                        bool one_stage_per_lane = false, bool two_stages_per_lane = false) {
+// redo_parity: the caller's launch counter bit for m.REDO (toggled here by every launch that uses it).
+static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
+                        int* redo_parity, bool one_stage_per_lane = false, bool two_stages_per_lane = false) {
     const int N = c.N;
     const bool sqp = sqp_max_iter > 1;
     seq = seq && !sqp;
+    Mem m = m_in;
+    m.redo_parity = *redo_parity;
+    // the sequential kernel over the instances the scan kernel declined (two stages per lane, group
+    // width by horizon); same grid as a full launch, blocks beyond the list return at once
+#define MPC_LAUNCH_LIST()                                                                                                 \
+    do {                                                                                                                  \
+        const int gw = N + 1 <= 32 ? 16 : N + 1 <= 64 ? 32 : 64;                                                          \
+        const int per = 64 / gw;                                                                                          \
+        const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
+        if (sqp) {                                                                                                        \
+            if (gw == 16) hipLaunchKernelGGL((k_wave2<16, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+            else if (gw == 32) hipLaunchKernelGGL((k_wave2<32, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
+            else hipLaunchKernelGGL((k_wave2<64, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
+        } else {                                                                                                          \
+            if (gw == 16) hipLaunchKernelGGL((k_wave2<16, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+            else if (gw == 32) hipLaunchKernelGGL((k_wave2<32, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
+            else hipLaunchKernelGGL((k_wave2<64, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
+        }                                                                                                                 \
+        *redo_parity ^= 1;                                                                                                \
+    } while (0)
 #define MPC_LAUNCH_WAVE(X_)                                                                                               \
     do {                                                                                                                  \
         const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                        \
         if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
-        else if (seq) hipLaunchKernelGGL((k_wave<X_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);        \
         else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                  \
+        MPC_LAUNCH_LIST();                                                                                                \
     } while (0)
 #define MPC_LAUNCH_WAVE2(GW_)                                                                                             \
     do {                                                                                                                  \
         const int per = 64 / GW_;                                                                                         \
         const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
-        if (seq) hipLaunchKernelGGL((k_wave2<GW_, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);           \
-        else hipLaunchKernelGGL((k_wave2<GW_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                \
+        if (seq) {                                                                                                        \
+            hipLaunchKernelGGL((k_wave2<GW_, false, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);         \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL((k_wave2<GW_, true, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);          \
+            MPC_LAUNCH_LIST();                                                                                            \
+        }                                                                                                                 \
     } while (0)
-    if (N + 1 > 64) {
+    if (seq) {
+        // the sequential model (cross-check; RTI only): sequential recursions + refinement, two stages per lane
+        if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
+        else if (N + 1 <= 64) MPC_LAUNCH_WAVE2(32);
+        else MPC_LAUNCH_WAVE2(64);
+    } else if (N + 1 > 64) {
         // 64 <= N <= 127: two stages per lane, one OCP per wavefront
         const dim3 grd(n), blk(64);
-        if (sqp) hipLaunchKernelGGL((k_wave2<64, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
-        else MPC_LAUNCH_WAVE2(64);
+        if (sqp) {
+            hipLaunchKernelGGL((k_wave2<64, true, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
+            MPC_LAUNCH_LIST();
+        } else MPC_LAUNCH_WAVE2(64);
     } else if (one_stage_per_lane || sqp || N + 1 <= 16 ||
                (!two_stages_per_lane && n / (N + 1 <= 32 ? 2 : 1) <= 4 * MPC_SIMD_SLOTS)) {
         // One stage per lane: N + 1 <= 16 fills a 16-lane group as it is (four OCPs per wavefront
@@ -1064,6 +1143,7 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
         if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
         else MPC_LAUNCH_WAVE2(32);
     }
+#undef MPC_LAUNCH_LIST
 #undef MPC_LAUNCH_WAVE
 #undef MPC_LAUNCH_WAVE2
 }
@@ -1071,7 +1151,7 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
 static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
     HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
     launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ || model == MPC_MODEL_WAVE2_SEQ, st,
-                model == MPC_MODEL_WAVE1 || model == MPC_MODEL_WAVE_SEQ, model == MPC_MODEL_WAVE2 || model == MPC_MODEL_WAVE2_SEQ);
+                &s.redo_parity, model == MPC_MODEL_WAVE1, model == MPC_MODEL_WAVE2);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1678,10 +1758,12 @@ size_t mpc_batch_device_bytes(const mpc_batch_t* h) {
 struct StaticScratch {
     double cap[(size_t)MPC_STATIC_MAX_LINES * MPC_CAP];   // capsule lines [instance][stage 0..N][8]
     int status[MPC_STATIC_MAX_B], qp_iter[MPC_STATIC_MAX_B], diag[MPC_STATIC_MAX_B];
+    int redo[MPC_REDO_LIST + MPC_STATIC_MAX_B];   // Mem::REDO (zero when the module is loaded)
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
 #define MPC_STATIC_MAX_DEVICES 64
 static StaticScratch* g_scratch_ptr[MPC_STATIC_MAX_DEVICES];
+static int g_scratch_parity[MPC_STATIC_MAX_DEVICES];   // Mem::redo_parity of the next launch on that device
 static std::mutex g_scratch_mutex;
 // The current device's copy of `scratch` (set-up on the first call on that device), or null.
 static StaticScratch* static_scratch(int dev) {
@@ -1729,6 +1811,7 @@ int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const do
     memset(&m, 0, sizeof(m));
     m.cap = sc->cap;
     m.STATUS = sc->status; m.QPITER = sc->qp_iter; m.DIAG = sc->diag;
+    m.REDO = sc->redo;
     if (cold) {   // the all-zero iterate of a fresh capsule (acados_solver_mobile_robot.c:703-729)
         const hipError_t e = hipMemsetAsync(sc->cap, 0, sizeof(double) * MPC_CAP * (size_t)B * (N + 1), st);
         if (e != hipSuccess) {
@@ -1737,7 +1820,10 @@ int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const do
         }
     }
     const WaveIO io = {d_x0, d_yref, d_yref_e, d_u0, d_status, d_qp_iter};
-    launch_wave(make_consts(*spec), m, B, 1, io, false, st);
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);   // (calls that overlap on one GPU race anyway: see the header)
+        launch_wave(make_consts(*spec), m, B, 1, io, false, st, &g_scratch_parity[dev]);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fprintf(stderr, "mpc_batch_solve_static: launch: %s\n", hipGetErrorString(e));

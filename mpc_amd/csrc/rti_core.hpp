@@ -104,10 +104,16 @@ struct Mem {
     double* cap;
     double* lam;         // [instance][stage 0..N][8] bound multipliers, full-SQP handles only (else null)
     double* u0;          // [S][2] u_0 of the last solve (the previous one where the QP failed)
+    // Instances whose scan step was declined (rti_wave2.hpp iterate): REDO[0], REDO[1] = two counters
+    // used by alternate launches (launch t counts in REDO[t & 1] and clears the other one for launch
+    // t + 1, so no memset sits between two solves), REDO[MPC_REDO_LIST + n] = the n-th instance.
+    int* REDO;
+    int redo_parity;
 };
+enum { MPC_REDO_LIST = 64 };
 enum : int { MPC_CAP = 8, C_X = 0, C_U = 3, C_PI = 5 };
 
-// MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK: include/mpc_batch.h
+// MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK / MPC_DIAG_ITREF_SKIPPED: include/mpc_batch.h
 
 // ------------------------------------------------------------------------------------
 // Per-stage algebra shared by the two execution models (one OCP per lane: Lane below; one OCP
@@ -882,7 +888,7 @@ struct Lane : Algebra {
             sweep_fw<true>(2, sigma_mu, fc);
             alpha = fc.a_prim < fc.a_dual ? fc.a_prim : fc.a_dual;
         }
-        if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF;
+        if (!(fc.lin_g < c.itref_tol_g)) s.diag |= MPC_DIAG_ITREF_SKIPPED;
         if (!(fc.lin_g < c.lq_tol)) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
         double a_upd = alpha;

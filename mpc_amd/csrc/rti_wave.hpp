@@ -199,7 +199,7 @@ struct Wave : Algebra {
     double dza[4], dz[5], dpi[3];
     double ti[8];                // 1 / t of the current slacks (same bits as recomputing it in every pass)
     int wdiag = 0;               // MPC_DIAG_* bits raised inside the sweeps
-    bool seq_now = false;        // SCAN build: use the sequential recursions (fallback of one iteration)
+    static constexpr bool seq_now = false;   // (the in-kernel sequential redo of an iteration is gone: see iterate)
     mc_d2* mc = nullptr;         // this lane's column of the product cache (X::MCACHE)
     // 1.0 where this stage has input bounds (k < N) / state bounds (0 < k < N), else 0.0.  Entries
     // without a bound carry lam = 0, t = 1; scaling sigma*mu, the step length and the lam clamp by
@@ -212,6 +212,7 @@ struct Wave : Algebra {
         double alpha, mu;
         double musum;   // sum of lam*t over all bounds
         bool open;      // some residual norm is above its tolerance (the norm part of HPIPM's loop condition)
+        bool declined;  // SCAN: the scan step of this iteration was not accurate enough (see iterate)
     };
 
     __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_, mc_d2* mc_ = nullptr)
@@ -1051,6 +1052,13 @@ struct Wave : Algebra {
                 const double lg0 = c.wg[0] * dl[0] + rg[0] + dlam_net[0] + (ab.B00 * dp0 + ab.B10 * dp1 + ab.B20 * dp2);
                 const double lg1 = c.wg[1] * dl[1] + rg[1] + dlam_net[1] + (ab.B01 * dp0 + ab.B11 * dp1 + ab.B21 * dp2);
                 lin_g = amax(lin_g, lg0); lin_g = amax(lin_g, lg1);
+                if (SCAN) {
+                    // dynamics row: the next stage's dx is what the scan delivered (nx), checked
+                    // against this stage's own step
+                    lin_g = amax(lin_g, rb[0] + (ab.B00 * dl[0] + ab.B01 * dl[1] + (dl[2] + ab.a * dl[4])) - nx0);
+                    lin_g = amax(lin_g, rb[1] + (ab.B10 * dl[0] + ab.B11 * dl[1] + (dl[3] + ab.b * dl[4])) - nx1);
+                    lin_g = amax(lin_g, rb[2] + (ab.B20 * dl[0] + ab.B21 * dl[1] + dl[4]) - nx2);
+                }
                 if (!is0) {
                     const double lg2 = c.wg[2] * dl[2] + rg[2] + dlam_net[2] - dpm0 + dp0;
                     const double lg3 = c.wg[3] * dl[3] + rg[3] + dlam_net[3] - dpm1 + dp1;
@@ -1118,65 +1126,44 @@ struct Wave : Algebra {
         s.alpha = 1.0;
         s.kk = 0;
         s.diag = 0;
+        s.declined = false;
     }
     __device__ __forceinline__ bool cont(const State& s) const {
-        return s.kk < c.iter_max && s.alpha > c.alpha_min && s.open;
+        return s.kk < c.iter_max && s.alpha > c.alpha_min && s.open && !s.declined;
     }
-    // Barrier terms of the current point (what BU hands to the factorisation), recomputed for the
-    // sequential redo of an iteration.
-    __device__ __forceinline__ void refactor_seq() {
-        double Gam[4], gam[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Con q;
-            con_cached(j, q);
-            const bool hb = has_bound(j);
-            Gam[j] = hb ? con_Gamma(q) : 0.0;
-            gam[j] = hb ? con_gamma(q) : 0.0;
-        }
-        factor_seq(Gam, gam);
-    }
-
+    // One IPM iteration.  SCAN build: the stationarity and dynamics rows of the linearised KKT
+    // system (lin_g; what HPIPM's refinement loop tests against 1e-6 / 1e-8) are checked against
+    // 1e-8.  If the scans were not accurate enough (strongly active state bounds) NOTHING has
+    // changed and the instance stops (s.declined): the kernel hands it to the sequential kernel
+    // (k_wave2<.., SCAN = false, .., LIST = true>, rti_wave2.hpp), which redoes the whole QP with
+    // the sequential recursions and HPIPM's iterative refinement.
     __device__ __forceinline__ void iterate(State& s) {
         const double nci = nc_inv();
         int mode = 1;
         FwdOut fc;
         double alpha = 0.0, sigma_mu = 0.0;
-        // The search direction.  SCAN build: the stationarity residual of the linear system
-        // (lin_g, what HPIPM's refinement loop tests against 1e-6) is checked against 1e-8; if the
-        // scans were not accurate enough (strongly active state bounds), the iteration is redone
-        // once with the sequential recursions.  A loop, not two inlined copies (code size).
+        factor_now();
+        FwdOut fa;
+        fw<false>(0, 0.0, fa);
+        const double a_aff = fa.alpha;
+        const double mu_aff0 = (s.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
+        const double tmp = mu_aff0 / s.mu;
+        const double sigma = tmp * tmp * tmp;
+        sigma_mu = sigma * s.mu;
+        if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+        // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
 #pragma nounroll
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if (attempt == 0) {
-                factor_now();
-            } else {
-                wdiag |= MPC_DIAG_SCAN_FALLBACK;
-                seq_now = true;
-                refactor_seq();
-            }
-            FwdOut fa;
-            fw<false>(0, 0.0, fa);
-            const double a_aff = fa.alpha;
-            const double mu_aff0 = (s.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
-            const double tmp = mu_aff0 / s.mu;
-            const double sigma = tmp * tmp * tmp;
-            sigma_mu = sigma * s.mu;
-            if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
-            // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
-            mode = 1;
-#pragma nounroll
-            for (;;) {
-                bw(mode, sigma_mu);
-                fw<true>(mode, sigma_mu, fc, s.musum, mu_aff0, SCAN && attempt == 0);
-                alpha = fc.alpha;
-                if (!fc.redo_centering) break;
-                mode = 2;
-            }
-            if (fc.accepted) break;
+        for (;;) {
+            bw(mode, sigma_mu);
+            fw<true>(mode, sigma_mu, fc, s.musum, mu_aff0, SCAN);
+            alpha = fc.alpha;
+            if (!fc.redo_centering) break;
+            mode = 2;
         }
-        seq_now = false;
-        if (fc.lin_itref) s.diag |= MPC_DIAG_ITREF;
+        if (!fc.accepted) {
+            s.declined = true;
+            return;
+        }
         if (fc.lin_lq) s.diag |= MPC_DIAG_LQ;
         s.alpha = alpha;
         bu(s.musum, s.open);

@@ -75,6 +75,7 @@ struct Wave2 : Algebra {
         int kk, diag;
         double alpha, mu, musum;
         bool open;
+        bool declined;   // SCAN only: the scan step of this iteration was not accurate enough (see iterate)
     };
 
     __device__ __forceinline__ Wave2(const Consts& c_, int lane_in_group, mc_d2* mc_)
@@ -429,18 +430,21 @@ struct Wave2 : Algebra {
 
     // ---- sequential recursions over the stages (fallback of the acceptance test / WAVE_SEQ) ----
     // One stage of the backward recursion: in (P, p) of stage j + 1, out (P, p) of stage j.
-    __device__ __forceinline__ void seq_back(Stg& t, const double Gam[4], const double hup[2], const double hxp[2],
+    // Right-hand side of the stage: g5 = gradient part (u0, u1, x, y, psi; barrier terms included),
+    // rb = dynamics part.  (The IPM direction passes its residuals, the refinement the residual of
+    // the linear system itself.)
+    __device__ __forceinline__ void seq_back(Stg& t, const double Gam[4], const double g5[5], const double rb[3],
                                              bool factorise, Sym3& P, double p[3]) {
         if (t.mid) {
             if (factorise) t.P = P;
             t.pv[0] = p[0]; t.pv[1] = p[1]; t.pv[2] = p[2];
             const AB8& ab = t.ab;
             const Sym3& Q = t.P;
-            const double w0 = Q.p00 * t.rb[0] + Q.p10 * t.rb[1] + Q.p20 * t.rb[2] + p[0];
-            const double w1 = Q.p10 * t.rb[0] + Q.p11 * t.rb[1] + Q.p21 * t.rb[2] + p[1];
-            const double w2 = Q.p20 * t.rb[0] + Q.p21 * t.rb[1] + Q.p22 * t.rb[2] + p[2];
-            const double hu0 = hup[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
-            const double hu1 = hup[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
+            const double w0 = Q.p00 * rb[0] + Q.p10 * rb[1] + Q.p20 * rb[2] + p[0];
+            const double w1 = Q.p10 * rb[0] + Q.p11 * rb[1] + Q.p21 * rb[2] + p[1];
+            const double w2 = Q.p20 * rb[0] + Q.p21 * rb[1] + Q.p22 * rb[2] + p[2];
+            const double hu0 = g5[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
+            const double hu1 = g5[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
             if (factorise) {
                 Gain g;
                 gain(t.P, ab, Gam[0], Gam[1], true, g);
@@ -449,19 +453,19 @@ struct Wave2 : Algebra {
             }
             solve2(t.id0, t.l10, t.id1, hu0, hu1, t.kff[0], t.kff[1]);
             if (!t.is0) {
-                const double hx0 = hxp[0] + w0;
-                const double hx1 = hxp[1] + w1;
-                const double hx2 = t.rg[4] + (ab.a * w0 + ab.b * w1 + w2);
+                const double hx0 = g5[2] + w0;
+                const double hx1 = g5[3] + w1;
+                const double hx2 = g5[4] + (ab.a * w0 + ab.b * w1 + w2);
                 p[0] = hx0 + (t.K00 * hu0 + t.K10 * hu1);
                 p[1] = hx1 + (t.K01 * hu0 + t.K11 * hu1);
                 p[2] = hx2 + (t.K02 * hu0 + t.K12 * hu1);
             }
         } else if (t.isN) {
             if (factorise) P = terminal_P();
-            p[0] = t.rg[2]; p[1] = t.rg[3]; p[2] = t.rg[4];
+            p[0] = g5[2]; p[1] = g5[3]; p[2] = g5[4];
         }
     }
-    __device__ __forceinline__ void back_seq(const double Gam[2][4], const double hup[2][2], const double hxp[2][2], bool factorise) {
+    __device__ __forceinline__ void back_seq(const double Gam[2][4], const double g5[2][5], const double rb[2][3], bool factorise) {
         Sym3 Po = terminal_P();
         double po[3] = {0.0, 0.0, 0.0};
         for (int kl = Nl; kl >= 0; --kl) {
@@ -471,11 +475,21 @@ struct Wave2 : Algebra {
                 Sym3 P;
                 P.p00 = sh[0]; P.p10 = sh[1]; P.p11 = sh[2]; P.p20 = sh[3]; P.p21 = sh[4]; P.p22 = sh[5];
                 double p[3] = {sh[6], sh[7], sh[8]};
-                seq_back(s[1], Gam[1], hup[1], hxp[1], factorise, P, p);
-                seq_back(s[0], Gam[0], hup[0], hxp[0], factorise, P, p);
+                seq_back(s[1], Gam[1], g5[1], rb[1], factorise, P, p);
+                seq_back(s[0], Gam[0], g5[0], rb[0], factorise, P, p);
                 Po = P; po[0] = p[0]; po[1] = p[1]; po[2] = p[2];
             }
         }
+    }
+    // the IPM direction's right-hand side: residuals of the stage + barrier terms
+    __device__ __forceinline__ void back_seq_ipm(const double Gam[2][4], const double hup[2][2], const double hxp[2][2], bool factorise) {
+        double g5[2][5], rb[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            g5[e][0] = hup[e][0]; g5[e][1] = hup[e][1]; g5[e][2] = hxp[e][0]; g5[e][3] = hxp[e][1]; g5[e][4] = s[e].rg[4];
+            rb[e][0] = s[e].rb[0]; rb[e][1] = s[e].rb[1]; rb[e][2] = s[e].rb[2];
+        }
+        back_seq(Gam, g5, rb, factorise);
     }
     __device__ __forceinline__ void factor_seq(const double Gam[2][4], const double gam[2][4]) {
         double hup[2][2], hxp[2][2];
@@ -484,10 +498,10 @@ struct Wave2 : Algebra {
             hup[e][0] = s[e].rg[0] + gam[e][0]; hup[e][1] = s[e].rg[1] + gam[e][1];
             hxp[e][0] = s[e].rg[2] + gam[e][2]; hxp[e][1] = s[e].rg[3] + gam[e][3];
         }
-        back_seq(Gam, hup, hxp, true);
+        back_seq_ipm(Gam, hup, hxp, true);
     }
     // one stage of the forward recursion: in dx of stage j, out dx of stage j + 1
-    __device__ __forceinline__ void seq_fwd(const Stg& t, double dx[3], double dl[5]) const {
+    __device__ __forceinline__ void seq_fwd(const Stg& t, const double rb[3], double dx[3], double dl[5]) const {
         if (t.mid) {
             double du0 = t.kff[0], du1 = t.kff[1];
             if (!t.is0) {
@@ -498,28 +512,32 @@ struct Wave2 : Algebra {
             }
             dl[0] = du0; dl[1] = du1; dl[2] = dx[0]; dl[3] = dx[1]; dl[4] = dx[2];
             const AB8& ab = t.ab;
-            const double n0 = t.rb[0] + (ab.B00 * du0 + ab.B01 * du1 + (dx[0] + ab.a * dx[2]));
-            const double n1 = t.rb[1] + (ab.B10 * du0 + ab.B11 * du1 + (dx[1] + ab.b * dx[2]));
-            const double n2 = t.rb[2] + (ab.B20 * du0 + ab.B21 * du1 + dx[2]);
+            const double n0 = rb[0] + (ab.B00 * du0 + ab.B01 * du1 + (dx[0] + ab.a * dx[2]));
+            const double n1 = rb[1] + (ab.B10 * du0 + ab.B11 * du1 + (dx[1] + ab.b * dx[2]));
+            const double n2 = rb[2] + (ab.B20 * du0 + ab.B21 * du1 + dx[2]);
             dx[0] = n0; dx[1] = n1; dx[2] = n2;
         } else if (t.isN) {
             dl[2] = dx[0]; dl[3] = dx[1]; dl[4] = dx[2];
         }
     }
-    __device__ __forceinline__ void fwd_seq(double nx[2][3], double dl[2][5]) const {
+    __device__ __forceinline__ void fwd_seq(const double rb[2][3], double nx[2][3], double dl[2][5]) const {
         double out[3] = {0.0, 0.0, 0.0};
         for (int kl = 0; kl <= Nl; ++kl) {
             double sh[3] = {out[0], out[1], out[2]};
             x.prev(sh);
             if (k == kl) {
                 double dx[3] = {sh[0], sh[1], sh[2]};
-                seq_fwd(s[0], dx, dl[0]);
+                seq_fwd(s[0], rb[0], dx, dl[0]);
                 nx[0][0] = dx[0]; nx[0][1] = dx[1]; nx[0][2] = dx[2];
-                seq_fwd(s[1], dx, dl[1]);
+                seq_fwd(s[1], rb[1], dx, dl[1]);
                 nx[1][0] = dx[0]; nx[1][1] = dx[1]; nx[1][2] = dx[2];
                 out[0] = dx[0]; out[1] = dx[1]; out[2] = dx[2];
             }
         }
+    }
+    __device__ __forceinline__ void fwd_seq_ipm(double nx[2][3], double dl[2][5]) const {
+        const double rb[2][3] = {{s[0].rb[0], s[0].rb[1], s[0].rb[2]}, {s[1].rb[0], s[1].rb[1], s[1].rb[2]}};
+        fwd_seq(rb, nx, dl);
     }
 
     // ================= parallel-in-time versions (see rti_wave.hpp for the method) =================
@@ -907,14 +925,14 @@ struct Wave2 : Algebra {
         if (US) rhs_scan<false>(hup, hxp);
         else {
             const double Gam0[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            back_seq(Gam0, hup, hxp, false);
+            back_seq_ipm(Gam0, hup, hxp, false);
         }
     }
 
     // ---- FW: forward substitution, step lengths and the mu_aff sums, both stages (Wave::fw) ----
     struct FwdOut {
         double alpha, s1, s2;
-        bool lin_itref, lin_lq, lin_scan;
+        bool lin_itref, lin_lq, lin_scan;   // refinement performed / residual beyond HPIPM's LQ switch / scan step declined
         bool redo_centering;
         bool accepted;
     };
@@ -924,7 +942,7 @@ struct Wave2 : Algebra {
         double nx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         double dl[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
         if (US) fwd_scan(nx, dl);
-        else fwd_seq(nx, dl);
+        else fwd_seq_ipm(nx, dl);
         double ginv = 1.0;
         double dn = 1.0, dd = -1.0;
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
@@ -952,8 +970,9 @@ struct Wave2 : Algebra {
                     ginv = fmax(ginv, 1.0 + gl);
                     ginv = fmax(ginv, 1.0 + gu);
                 }
-                s1 += q.lam_l * sp.dt_l + q.t_l * sp.dl_l;
-                s1 += q.lam_u * sp.dt_u + q.t_u * sp.dl_u;
+                const double cl = q.lam_l * sp.dt_l + q.t_l * sp.dl_l, cu = q.lam_u * sp.dt_u + q.t_u * sp.dl_u;
+                s1 += cl;
+                s1 += cu;
                 s2 += sp.dl_l * sp.dt_l;
                 s2 += sp.dl_u * sp.dt_u;
                 dlam_net[e][j] = sp.dl_u - sp.dl_l;
@@ -979,6 +998,11 @@ struct Wave2 : Algebra {
                 const double* dpm = e == 0 ? dpm0 : dpi[0];
                 const double* d = dl[e];
                 if (t.mid) {
+                    // dynamics: the next stage's dx is what the scan delivered to it (nx), checked
+                    // against this stage's own step
+                    lin_g = amax(lin_g, t.rb[0] + (ab.B00 * d[0] + ab.B01 * d[1] + (d[2] + ab.a * d[4])) - nx[e][0]);
+                    lin_g = amax(lin_g, t.rb[1] + (ab.B10 * d[0] + ab.B11 * d[1] + (d[3] + ab.b * d[4])) - nx[e][1]);
+                    lin_g = amax(lin_g, t.rb[2] + (ab.B20 * d[0] + ab.B21 * d[1] + d[4]) - nx[e][2]);
                     const double lg0 = c.wg[0] * d[0] + t.rg[0] + dlam_net[e][0] + (ab.B00 * dp[0] + ab.B10 * dp[1] + ab.B20 * dp[2]);
                     const double lg1 = c.wg[1] * d[1] + t.rg[1] + dlam_net[e][1] + (ab.B01 * dp[0] + ab.B11 * dp[1] + ab.B21 * dp[2]);
                     lin_g = amax(lin_g, lg0); lin_g = amax(lin_g, lg1);
@@ -1002,9 +1026,16 @@ struct Wave2 : Algebra {
         x.rmax(am);
         x.rsum(as);
         o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
-        o.lin_itref = FINAL ? x.gany(!(lin_g < K::itref_tol_g)) : false;
+        // The scan step is taken only if the stationarity and dynamics rows of the linearised KKT
+        // system (lin_g holds the larger of the two norms) are met to 1e-8 — 100x tighter than /
+        // equal to where HPIPM's refinement loop would stop at once.  The slack and complementarity
+        // rows are met to rounding by construction (dt and dlam are computed FROM those rows, lane by
+        // lane, by the same code on either path; adding their norms here was measured at +6 % kernel
+        // time) and are checked where refinement can act on them, on the sequential path.
+        // A declined instance is solved again by the sequential kernel, which refines as HPIPM does.
+        o.lin_itref = false;
         o.lin_lq = FINAL ? x.gany(!(lin_g < K::lq_tol)) : false;
-        o.lin_scan = (FINAL && US) ? x.gany(!(lin_g < K::scan_tol_lin)) : false;
+        o.lin_scan = FINAL ? x.gany(!(lin_g < K::scan_tol_lin)) : false;
         o.redo_centering = false;
         o.accepted = false;
         if (FINAL) {
@@ -1054,6 +1085,212 @@ struct Wave2 : Algebra {
         }
     }
 
+    // ---- the corrector's forward pass on the SEQUENTIAL path, with HPIPM's iterative refinement
+    //      of the search direction (OCP_QP_IPM_DELTA_STEP with itref_corr_max = 2, BALANCE mode:
+    //      acados_solver_mobile_robot.c:670; restated in oracle/mpc_oracle.hpp delta_step).
+    // The step (dz, dpi, dlam, dt) is held explicitly; while the residual of the linearised KKT
+    // system exceeds (res_g_max, res_b_max, res_d_max, res_m_max) the system is solved again for that
+    // residual with the same factorisation and the solution added, at most twice; then the step
+    // lengths are recomputed and the step is taken.  Cold code: only instances whose scan step was
+    // declined, and the WAVE2_SEQ model, come here.
+    struct Resid { double g[2][5], b[2][3], dl[2][4], du[2][4], ml[2][4], mu[2][4]; };
+    __device__ __forceinline__ void step_lengths(const Con (&cq)[2][4], const Step (&sp)[2][4], FwdOut& o) const {
+        double ginv = 1.0, dn = 1.0, dd = -1.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Con& q = cq[e][j];
+                const Step& p = sp[e][j];
+                const double f = bf(s[e], j);
+                ginv = fmax(ginv, -((p.dt_l * q.ti_l) * f));
+                ginv = fmax(ginv, -((p.dt_u * q.ti_u) * f));
+                if (dn * p.dl_l < q.lam_l * dd) { dn = q.lam_l; dd = p.dl_l; }
+                if (dn * p.dl_u < q.lam_u * dd) { dn = q.lam_u; dd = p.dl_u; }
+                s1 += q.lam_l * p.dt_l + q.t_l * p.dl_l;
+                s1 += q.lam_u * p.dt_u + q.t_u * p.dl_u;
+                s2 += p.dl_l * p.dt_l;
+                s2 += p.dl_u * p.dt_u;
+            }
+        double am[1] = {fmax(ginv, -(dd * rcp(dn)))}, as[2] = {s1, s2};
+        x.rmax(am);
+        x.rsum(as);
+        o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
+    }
+    // dpi of both stages from the value function: dpi_j = P_{j+1} dx_{j+1} + p_{j+1}
+    __device__ __forceinline__ void step_pi(const double nx[2][3], double dpi[2][3]) const {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const Stg& t = s[e];
+            const Sym3& P = t.P;
+            dpi[e][0] = t.mid ? P.p00 * nx[e][0] + P.p10 * nx[e][1] + P.p20 * nx[e][2] + t.pv[0] : 0.0;
+            dpi[e][1] = t.mid ? P.p10 * nx[e][0] + P.p11 * nx[e][1] + P.p21 * nx[e][2] + t.pv[1] : 0.0;
+            dpi[e][2] = t.mid ? P.p20 * nx[e][0] + P.p21 * nx[e][1] + P.p22 * nx[e][2] + t.pv[2] : 0.0;
+        }
+    }
+    // OCP_QP_RES_COMPUTE_LIN: residual of the linearised KKT system at the step; n = inf-norms (g, b, d, m)
+    __device__ __forceinline__ void lin_residual(const Con (&cq)[2][4], const Step (&sp)[2][4], const double dz[2][5],
+                                                 const double dpi[2][3], Resid& r, double n[4]) const {
+        double dpm0[3] = {dpi[1][0], dpi[1][1], dpi[1][2]};   // -> dpi of stage 2k - 1
+        double dxn1[3] = {dz[0][2], dz[0][3], dz[0][4]};      // -> dx of stage 2k + 2
+        x.prev(dpm0);
+        x.next(dxn1);
+        n[0] = n[1] = n[2] = n[3] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const Stg& t = s[e];
+            const AB8& ab = t.ab;
+            const double* dp = dpi[e];
+            const double* dpm = e == 0 ? dpm0 : dpi[0];
+            const double* dxn = e == 0 ? &dz[1][2] : dxn1;
+            const double* d = dz[e];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r.g[e][q] = 0.0;
+            r.b[e][0] = r.b[e][1] = r.b[e][2] = 0.0;
+            if (t.mid) {
+                r.g[e][0] = c.wg[0] * d[0] + t.rg[0] + (sp[e][0].dl_u - sp[e][0].dl_l) + (ab.B00 * dp[0] + ab.B10 * dp[1] + ab.B20 * dp[2]);
+                r.g[e][1] = c.wg[1] * d[1] + t.rg[1] + (sp[e][1].dl_u - sp[e][1].dl_l) + (ab.B01 * dp[0] + ab.B11 * dp[1] + ab.B21 * dp[2]);
+                if (!t.is0) {
+                    r.g[e][2] = c.wg[2] * d[2] + t.rg[2] + (sp[e][2].dl_u - sp[e][2].dl_l) - dpm[0] + dp[0];
+                    r.g[e][3] = c.wg[3] * d[3] + t.rg[3] + (sp[e][3].dl_u - sp[e][3].dl_l) - dpm[1] + dp[1];
+                    r.g[e][4] = c.wg[4] * d[4] + t.rg[4] - dpm[2] + (ab.a * dp[0] + ab.b * dp[1] + dp[2]);
+                }
+                r.b[e][0] = t.rb[0] + (ab.B00 * d[0] + ab.B01 * d[1] + (d[2] + ab.a * d[4])) - dxn[0];
+                r.b[e][1] = t.rb[1] + (ab.B10 * d[0] + ab.B11 * d[1] + (d[3] + ab.b * d[4])) - dxn[1];
+                r.b[e][2] = t.rb[2] + (ab.B20 * d[0] + ab.B21 * d[1] + d[4]) - dxn[2];
+            } else if (t.isN) {
+                r.g[e][2] = c.we[0] * d[2] + t.rg[2] - dpm[0];
+                r.g[e][3] = c.we[1] * d[3] + t.rg[3] - dpm[1];
+                r.g[e][4] = c.we[2] * d[4] + t.rg[4] - dpm[2];
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) n[0] = amax(n[0], r.g[e][q]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) n[1] = amax(n[1], r.b[e][q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Con& q = cq[e][j];
+                const Step& p = sp[e][j];
+                const double f = bf(t, j);
+                r.dl[e][j] = f * ((q.rd_l + p.dt_l) - d[j]);
+                r.du[e][j] = f * ((q.rd_u + p.dt_u) + d[j]);
+                r.ml[e][j] = f * (q.rm_l + (q.lam_l * p.dt_l + q.t_l * p.dl_l));
+                r.mu[e][j] = f * (q.rm_u + (q.lam_u * p.dt_u + q.t_u * p.dl_u));
+                n[2] = amax(n[2], r.dl[e][j]); n[2] = amax(n[2], r.du[e][j]);
+                n[3] = amax(n[3], r.ml[e][j]); n[3] = amax(n[3], r.mu[e][j]);
+            }
+        }
+        double nn[4] = {n[0], n[1], n[2], n[3]};
+        x.rmax(nn);
+        n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; n[3] = nn[3];
+    }
+    __device__ __forceinline__ void fw_final_seq(int mode, double sigma_mu, FwdOut& o, double musum, double mu_aff0) {
+        double nx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        double dz[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
+        fwd_seq_ipm(nx, dz);
+        Con cq[2][4];
+        Step sp[2][4];
+        const Opq oq = opq();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double dza[4];
+            get_dza(e, dza);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                con_cached(s[e], j, cq[e][j], oq);
+                con_correct(cq[e][j], mode, dza[j], sigma_mu * bf(s[e], j));
+                con_step(cq[e][j], dz[e][j], sp[e][j]);
+            }
+        }
+        double dpi[2][3];
+        step_pi(nx, dpi);
+        step_lengths(cq, sp, o);
+        o.lin_itref = o.lin_lq = o.lin_scan = false;
+        o.redo_centering = false;
+        o.accepted = false;
+        if (mode == 1) {
+            const double mu_aff1 = (musum + o.alpha * o.s1 + (o.alpha * o.alpha) * o.s2) * nc_inv();
+            o.redo_centering = mu_aff1 > MPC_IPM_COND_PRED_CORR_FAC * mu_aff0;
+            if (o.redo_centering) return;
+        }
+        // iterative refinement
+        int itref = 0;
+#pragma nounroll
+        for (; itref < MPC_IPM_ITREF_CORR_MAX; ++itref) {
+            Resid r;
+            double n[4];
+            lin_residual(cq, sp, dz, dpi, r, n);
+            if (itref == 0) o.lin_lq = !(fmax(fmax(n[0], n[1]), fmax(n[2], n[3])) <= K::lq_tol);
+            if (n[0] < K::res_g_max && n[1] < K::res_b_max && n[2] < K::res_d_max && n[3] < K::res_m_max) break;
+            o.lin_itref = true;
+            // OCP_QP_SOLVE_KKT_STEP with the residual as right-hand side
+            Con rq[2][4];
+            double g5[2][5];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) g5[e][q] = r.g[e][q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rq[e][j] = cq[e][j];
+                    rq[e][j].rd_l = r.dl[e][j]; rq[e][j].rd_u = r.du[e][j];
+                    rq[e][j].rm_l = r.ml[e][j]; rq[e][j].rm_u = r.mu[e][j];
+                    g5[e][j] += con_gamma(rq[e][j]);
+                }
+            }
+            const double Gam0[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            back_seq(Gam0, g5, r.b, false);
+            double nxr[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+            double dzr[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
+            fwd_seq(r.b, nxr, dzr);
+            double dpr[2][3];
+            step_pi(nxr, dpr);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dz[e][q] += dzr[e][q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dpi[e][q] += dpr[e][q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Step pr;
+                    con_step(rq[e][j], dzr[e][j], pr);
+                    sp[e][j].dt_l += pr.dt_l; sp[e][j].dt_u += pr.dt_u;
+                    sp[e][j].dl_l += pr.dl_l; sp[e][j].dl_u += pr.dl_u;
+                }
+            }
+        }
+        if (itref > 0) step_lengths(cq, sp, o);
+        // UPDATE_VAR_QP
+        o.accepted = true;
+        double a_upd = o.alpha;
+        if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * MPC_IPM_STEP_SCALE_LO + a_upd * MPC_IPM_STEP_SCALE_HI);
+        double pi[2][3];
+        get_pi(pi);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            Stg& t = s[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Step& p = sp[e][j];
+                const double aj = a_upd * bf(t, j), lmin = K::lam_min * bf(t, j);
+                double ll = t.bn.lam[j] + aj * p.dl_l, lu = t.bn.lam[4 + j] + aj * p.dl_u;
+                double tl = t.bn.t[j] + aj * p.dt_l, tu = t.bn.t[4 + j] + aj * p.dt_u;
+                if (ll < lmin) ll = lmin;
+                if (lu < lmin) lu = lmin;
+                if (tl < K::t_min) tl = K::t_min;
+                if (tu < K::t_min) tu = K::t_min;
+                t.bn.lam[j] = ll; t.bn.lam[4 + j] = lu; t.bn.t[j] = tl; t.bn.t[4 + j] = tu;
+                t.ti[j] = rcp(tl); t.ti[4 + j] = rcp(tu);
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) t.z[q] = t.z[q] + a_upd * dz[e][q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pi[e][q] = pi[e][q] + a_upd * dpi[e][q];
+        }
+        set_pi(pi);
+    }
+
     // ---- the RTI step (Wave::begin / cont / iterate) ----
     __device__ __forceinline__ double nc_inv() const { return c.nc_inv; }
     __device__ __forceinline__ void begin(State& st) {
@@ -1062,9 +1299,10 @@ struct Wave2 : Algebra {
         st.alpha = 1.0;
         st.kk = 0;
         st.diag = 0;
+        st.declined = false;
     }
     __device__ __forceinline__ bool cont(const State& st) const {
-        return st.kk < c.iter_max && st.alpha > K::alpha_min && st.open;
+        return st.kk < c.iter_max && st.alpha > K::alpha_min && st.open && !st.declined;
     }
     // The search direction of one IPM iteration (OCP_QP_IPM_DELTA_STEP) and, if it is accepted,
     // the variable update.  US: with the parallel scans; the stationarity residual of the linear
@@ -1087,20 +1325,27 @@ struct Wave2 : Algebra {
 #pragma nounroll
         for (;;) {
             bw<US>(mode, sigma_mu);
-            fw<true, US>(mode, sigma_mu, fc, st.musum, mu_aff0, US);
+            if (US) fw<true, true>(mode, sigma_mu, fc, st.musum, mu_aff0, true);
+            else fw_final_seq(mode, sigma_mu, fc, st.musum, mu_aff0);
             alpha = fc.alpha;
             if (!fc.redo_centering) break;
             mode = 2;
         }
         return fc.accepted;
     }
+    // One IPM iteration.  SCAN: if the scan step is declined NOTHING has changed and the instance
+    // stops (st.declined): the kernel hands it to the sequential kernel (k_wave2<.., SCAN = false, ..,
+    // LIST = true>), which redoes the whole QP with the sequential recursions and HPIPM's refinement.
+    // The hot kernel carries no sequential code (its registers are all spoken for).
     __device__ __forceinline__ void iterate(State& st) {
         FwdOut fc;
         double alpha = 0.0;
-        bool done = false;
-        if (SCAN) done = direction<true>(st, fc, alpha);
-        if (!done) {
-            if (SCAN) wdiag |= MPC_DIAG_SCAN_FALLBACK;
+        if (SCAN) {
+            if (!direction<true>(st, fc, alpha)) {
+                st.declined = true;
+                return;
+            }
+        } else {
             direction<false>(st, fc, alpha);
         }
         if (fc.lin_itref) st.diag |= MPC_DIAG_ITREF;

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "mpc_amd", "csrc")
-inst = sys.argv[1] if len(sys.argv) > 1 else "k_wave2<32, true, false>"
+inst = sys.argv[1] if len(sys.argv) > 1 else "k_wave2<32, true, false, false>"
 name = inst.split("<")[0]
 src = open(os.path.join(CS, "mpc_batch.hip")).read()
 io = src[src.index("struct WaveIO {"):]
