@@ -1087,7 +1087,7 @@ struct Wave2 : Algebra {
 
     // ---- the corrector's forward pass on the SEQUENTIAL path, with HPIPM's iterative refinement
     //      of the search direction (OCP_QP_IPM_DELTA_STEP with itref_corr_max = 2, BALANCE mode:
-    //      acados_solver_mobile_robot.c:670; restated in oracle/mpc_oracle.hpp delta_step).
+    //      acados_solver_mobile_robot.c:670; HPIPM d_ocp_qp_ipm.c, the itref_corr_max loop).
     // The step (dz, dpi, dlam, dt) is held explicitly; while the residual of the linearised KKT
     // system exceeds (res_g_max, res_b_max, res_d_max, res_m_max) the system is solved again for that
     // residual with the same factorisation and the solution added, at most twice; then the step
