@@ -98,6 +98,9 @@ template <class X> __device__ __forceinline__ X make_policy(int) { return X(); }
 // required, status / qp_iter may be null): inputs are read straight from the caller's arrays
 // (the lane of stage k reads yref[i][k][0..4], coalesced) and u0 / status / qp_iter are written
 // straight back — a wave-model solve is one launch, no pack / unpack, no workspace in HBM.
+// what a scan kernel leaves in io.status for an instance it has handed to the list kernel (which
+// overwrites it); never seen by a caller
+#define MPC_STATUS_PENDING (-1)
 struct WaveIO {
     const double* x0;      // [B][3]
     const double* yref;    // [B][N][5]
@@ -165,7 +168,10 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         }
         if (!on) return;
         if (SCAN && s.declined) {   // nothing is written: the sequential kernel redoes this QP (k_wave2<.., LIST>)
-            if (k == 0) m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+            if (k == 0) {
+                m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+                if (io.status) io.status[i] = MPC_STATUS_PENDING;
+            }
             return;
         }
         if (k == 0) {
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     if (k == 0 && redo) {
         m.SQPITER[i] = sqp_it;
         m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        if (io.status) io.status[i] = MPC_STATUS_PENDING;
     }
     if (k == 0 && !redo) {
         m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
@@ -350,7 +357,10 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         const bool ok = (hs == 0 || hs == 1);
         status = ok ? 0 : 4;
         const bool redo = SCAN && s.declined;   // nothing is written; the list kernel redoes this QP
-        if (redo && inst && k == 0) m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        if (redo && inst && k == 0) {
+            m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+            if (io.status) io.status[i] = MPC_STATUS_PENDING;
+        }
         if (inst && k == 0 && !redo) {
             m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag | (LIST ? MPC_DIAG_SCAN_FALLBACK : 0); m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
     if (redo && inst && k == 0) {
         m.SQPITER[i] = sqp_it;
         m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        if (io.status) io.status[i] = MPC_STATUS_PENDING;
     }
     if (inst && k == 0 && !redo) {
         m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
@@ -834,6 +845,8 @@ __global__ __launch_bounds__(MPC_WAVE) void k_track_advance(Consts c, Mem m, Tra
 // ------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------
+#define MPC_MAX_CHUNKS 4
+#define MPC_CHUNK_MIN 16384   // instances: below two chunks of this size a solve is not split
 struct Shard {
     int device = -1;
     int first = 0;     // first global instance of this shard
@@ -842,6 +855,10 @@ struct Shard {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ph[2] = {};   // around the dominant solve kernel of the last solve
+    // host-pointer solves of large batches are pipelined in chunks: the inputs of chunk c + 1 travel
+    // on copy_stream while the kernels of chunk c run on `stream` (created on first use)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_chunk[MPC_MAX_CHUNKS] = {};
     int n_ph = 0;
     int sqp_rounds = 0;  // QP rounds of the last full-SQP solve (lane model)
     // allocated by mpc_batch_create: the capsules, the small per-instance arrays, u0
@@ -925,6 +942,8 @@ static void free_shard(Shard& s) {
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     for (hipEvent_t e : s.ev_ph) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.ev_chunk) if (e) (void)hipEventDestroy(e);
+    if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
     if (s.stream) (void)hipStreamDestroy(s.stream);
     s = Shard();
 }
@@ -935,6 +954,7 @@ static void sync_all(mpc_batch* h) {
     for (Shard& s : h->shards) {
         if (s.device < 0 || !s.stream) continue;
         (void)hipSetDevice(s.device);
+        if (s.copy_stream) (void)hipStreamSynchronize(s.copy_stream);
         (void)hipStreamSynchronize(s.stream);
     }
 }
@@ -1072,8 +1092,12 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
 // (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
 // redo_parity: the caller's launch counter bit for m.REDO (toggled here by every launch that uses it).
+// part: MPC_LAUNCH_BOTH, or the scan kernel / the list kernel alone (the batch = 1 latency path
+// launches the list kernel only when the scan kernel has declined something: io.status == PENDING).
+enum { MPC_LAUNCH_BOTH = 0, MPC_LAUNCH_SCAN = 1, MPC_LAUNCH_LIST_ONLY = 2 };
 static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
-                        int* redo_parity, bool one_stage_per_lane = false, bool two_stages_per_lane = false) {
+                        int* redo_parity, bool one_stage_per_lane = false, bool two_stages_per_lane = false,
+                        int part = MPC_LAUNCH_BOTH) {
     const int N = c.N;
     const bool sqp = sqp_max_iter > 1;
     seq = seq && !sqp;
@@ -1083,6 +1107,7 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
     // width by horizon); same grid as a full launch, blocks beyond the list return at once
 #define MPC_LAUNCH_LIST()                                                                                                 \
     do {                                                                                                                  \
+        if (part == MPC_LAUNCH_SCAN) break;                                                                               \
         const int gw = N + 1 <= 32 ? 16 : N + 1 <= 64 ? 32 : 64;                                                          \
         const int per = 64 / gw;                                                                                          \
         const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
@@ -1100,7 +1125,8 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
 #define MPC_LAUNCH_WAVE(X_)                                                                                               \
     do {                                                                                                                  \
         const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                        \
-        if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
+        if (part == MPC_LAUNCH_LIST_ONLY) {                                                                               \
+        } else if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);        \
         else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                  \
         MPC_LAUNCH_LIST();                                                                                                \
     } while (0)
@@ -1111,7 +1137,8 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
         if (seq) {                                                                                                        \
             hipLaunchKernelGGL((k_wave2<GW_, false, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);         \
         } else {                                                                                                          \
-            hipLaunchKernelGGL((k_wave2<GW_, true, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);          \
+            if (part != MPC_LAUNCH_LIST_ONLY)                                                                             \
+                hipLaunchKernelGGL((k_wave2<GW_, true, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
             MPC_LAUNCH_LIST();                                                                                            \
         }                                                                                                                 \
     } while (0)
@@ -1124,7 +1151,8 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
         // 64 <= N <= 127: two stages per lane, one OCP per wavefront
         const dim3 grd(n), blk(64);
         if (sqp) {
-            hipLaunchKernelGGL((k_wave2<64, true, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
+            if (part != MPC_LAUNCH_LIST_ONLY)
+                hipLaunchKernelGGL((k_wave2<64, true, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);
             MPC_LAUNCH_LIST();
         } else MPC_LAUNCH_WAVE2(64);
     } else if (one_stage_per_lane || sqp || N + 1 <= 16 ||
@@ -1148,10 +1176,27 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
 #undef MPC_LAUNCH_WAVE2
 }
 
-static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model) {
-    HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-    launch_wave(h->consts, s.mem, n, h->spec.sqp_max_iter, wio, model == MPC_MODEL_WAVE_SEQ || model == MPC_MODEL_WAVE2_SEQ, st,
-                &s.redo_parity, model == MPC_MODEL_WAVE1, model == MPC_MODEL_WAVE2);
+// The shard's per-instance arrays as seen by a launch that starts at instance i0 (chunked solves;
+// wave models only: the lane model's slab is blocked by wavefront).  REDO is shared: the list holds
+// indices relative to the slice, and the hot kernel and its list kernel get the same slice.
+static Mem mem_slice(const Mem& m, int i0, int N) {
+    Mem r = m;
+    const size_t o = (size_t)i0;
+    r.STATUS += o; r.QPITER += o; r.DIAG += o; r.SQPITER += o; r.ACTIVE += o;
+    r.NLPRES += 4 * o;
+    r.cap += o * (size_t)(N + 1) * MPC_CAP;
+    if (r.lam) r.lam += o * (size_t)(N + 1) * 8;
+    if (r.u0) r.u0 += 2 * o;
+    return r;
+}
+
+// wio: the arrays of the n instances of this launch (already offset); i0: where they sit in the shard
+static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const WaveIO& wio, int model, int i0 = 0, bool first = true,
+                        int part = MPC_LAUNCH_BOTH) {
+    if (first) HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
+    launch_wave(h->consts, i0 ? mem_slice(s.mem, i0, h->spec.N) : s.mem, n, h->spec.sqp_max_iter, wio,
+                model == MPC_MODEL_WAVE_SEQ || model == MPC_MODEL_WAVE2_SEQ, st,
+                &s.redo_parity, model == MPC_MODEL_WAVE1, model == MPC_MODEL_WAVE2, part);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1163,7 +1208,7 @@ static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
 // d_iter may be null.
 static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, const double* d_yref,
                          const double* d_yrefe, double* d_u0, double* d_xt, double* d_ut, int* d_status,
-                         int* d_iter, hipStream_t st) {
+                         int* d_iter, hipStream_t st, int part = MPC_LAUNCH_BOTH) {
     const int N = h->spec.N;
     const dim3 tb(32, 8);
     Mem& m = s.mem;
@@ -1173,7 +1218,7 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
     if (d_ut) pack_iter(m, N, st, d_ut, N, 2, (int)C_U, n);
     if (model != MPC_MODEL_LANE) {
         const WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
-        int rc = enqueue_wave(h, s, n, st, io, model);
+        int rc = enqueue_wave(h, s, n, st, io, model, 0, part != MPC_LAUNCH_LIST_ONLY, part);
         if (rc != 0) return rc;
     } else {
         int rc = ensure_lane(h, s, st);
@@ -1349,10 +1394,19 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         int* zst = reinterpret_cast<int*>(zu0 + 2 * (size_t)B);
         int* zit = zst + B;
         HIPCHK(h, hipEventRecord(s.ev0, s.stream));
-        int rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream);
+        // the scan kernel alone; the sequential list kernel follows only if something was declined
+        int rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_SCAN);
         if (rc != 0) { sync_all(h); return rc; }
         HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
+        bool pending = false;
+        for (int i = 0; i < B; ++i) pending = pending || zst[i] == MPC_STATUS_PENDING;
+        if (pending) {
+            rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_LIST_ONLY);
+            if (rc != 0) { sync_all(h); return rc; }
+            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+            HIPCHK(h, hipStreamSynchronize(s.stream));
+        }
         if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
         if (status) memcpy(status, zst, sizeof(int) * B);
         if (qp_iter) memcpy(qp_iter, zit, sizeof(int) * B);
@@ -1371,6 +1425,37 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             HIPCHK(h, hipSetDevice(s.device));
             int rc = ensure_staging(h, s, xtraj != nullptr);
             if (rc != 0) return rc;
+            const int model = pick_model(h);
+            const int nchunks = (model == MPC_MODEL_LANE || xtraj) ? 1 : n / MPC_CHUNK_MIN > MPC_MAX_CHUNKS ? MPC_MAX_CHUNKS
+                                                                         : n / MPC_CHUNK_MIN > 1 ? n / MPC_CHUNK_MIN : 1;
+            if (nchunks > 1) {
+                // Pipelined: chunk c + 1's inputs are copied (copy_stream) while chunk c is solved
+                // (stream).  With pageable host arrays every hipMemcpyAsync returns when its data has
+                // left the host buffer, so the loop below still runs one chunk ahead of the kernels.
+                if (!s.copy_stream) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+                    for (hipEvent_t& e : s.ev_chunk) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
+                HIPCHK(h, hipEventRecord(s.ev0, s.stream));
+                // the staging buffers may still be read by the previous solve's kernels
+                HIPCHK(h, hipStreamWaitEvent(s.copy_stream, s.ev0, 0));
+                const int per = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
+                for (int c = 0, i0 = 0; i0 < n; ++c, i0 += per) {
+                    const int nc = n - i0 < per ? n - i0 : per;
+                    const size_t oc = o + (size_t)i0;
+                    HIPCHK(h, hipMemcpyAsync(s.s_x0 + 3 * (size_t)i0, x0 + 3 * oc, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, s.copy_stream));
+                    HIPCHK(h, hipMemcpyAsync(s.s_yref + 5 * (size_t)N * i0, yref + 5 * N * oc, sizeof(double) * 5 * N * nc, hipMemcpyHostToDevice, s.copy_stream));
+                    HIPCHK(h, hipMemcpyAsync(s.s_yrefe + 3 * (size_t)i0, yref_e + 3 * oc, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, s.copy_stream));
+                    HIPCHK(h, hipEventRecord(s.ev_chunk[c], s.copy_stream));
+                    HIPCHK(h, hipStreamWaitEvent(s.stream, s.ev_chunk[c], 0));
+                    const WaveIO io = {s.s_x0 + 3 * (size_t)i0, s.s_yref + 5 * (size_t)N * i0, s.s_yrefe + 3 * (size_t)i0,
+                                       s.s_u0 + 2 * (size_t)i0, nullptr, nullptr};
+                    rc = enqueue_wave(h, s, nc, s.stream, io, model, i0, c == 0);
+                    if (rc != 0) return rc;
+                }
+                HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+                if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
+            } else {
             HIPCHK(h, hipMemcpyAsync(s.s_x0, x0 + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
             HIPCHK(h, hipMemcpyAsync(s.s_yref, yref + 5 * N * o, sizeof(double) * 5 * N * n, hipMemcpyHostToDevice, s.stream));
             HIPCHK(h, hipMemcpyAsync(s.s_yrefe, yref_e + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
@@ -1387,6 +1472,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             if (xtraj) {
                 HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
                 HIPCHK(h, hipMemcpyAsync(utraj + 2 * N * o, s.s_ut, sizeof(double) * 2 * N * n, hipMemcpyDeviceToHost, s.stream));
+            }
             }
             if (status) HIPCHK(h, hipMemcpyAsync(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
             if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter + o, s.mem.QPITER, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));

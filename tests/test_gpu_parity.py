@@ -683,6 +683,36 @@ def test_corrector_refinement_is_performed_on_the_device(oracle, name):
         s.close()
 
 
+def test_latency_path_runs_the_list_kernel_only_when_needed(oracle):
+    """Batches up to 64 go through pinned host memory and ONE launch of the scan kernel; the
+    sequential list kernel is launched behind it only if the scan kernel declined an instance
+    (status PENDING in the pinned array).  On a stress workload some instances are declined: the
+    results must equal the oracle's like everywhere else, the declined ones carry DIAG bit 4, and no
+    PENDING status ever reaches the caller."""
+    B = 64
+    sp, wl = workload.make("mobile_robot", B)
+    sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sp.W), W_e=tuple(1e4 * w for w in sp.W_e))
+    s = capi.BatchSolver(sp, B)
+    xo, uo = np.zeros((B, sp.N + 1, 3)), np.zeros((B, sp.N, 2))
+    declined = 0
+    for t in range(6):
+        x0, yref, yref_e = (a.copy() for a in wl.tick(t))
+        shift = x0[:, :2].copy()
+        x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+        ro = oracle.rti_batch(sp, x0, yref, yref_e, xo, uo)
+        rg = s.solve(x0, yref, yref_e)            # host pointers, no trajectories: the latency path
+        xg, ug, _ = s.get(B, want_pi=False)
+        dg = s.get_diag(B)
+        declined += int(((dg & 4) != 0).sum())
+        assert (rg["status"] >= 0).all() and np.array_equal(ro["status"], rg["status"]), t
+        same = ro["qp_iter"] == rg["qp_iter"]
+        assert same.mean() >= 0.98, t
+        assert np.abs(ug - ro["utraj"])[same].max() < TOL_HARD and np.abs(rg["u0"] - ro["u0"])[same].max() < TOL_HARD, t
+        xo, uo = ro["xtraj"], ro["utraj"]
+    assert declined > 0, "the workload no longer makes the scan kernel decline anything"
+    s.close()
+
+
 def test_diag_is_clean_on_the_bench_workload():
     """None of the diagnostic bits (refinement performed / LQ switch may have fired / solved again by
     the sequential kernel) is raised on the headline workload."""
