@@ -1426,7 +1426,10 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             int rc = ensure_staging(h, s, xtraj != nullptr);
             if (rc != 0) return rc;
             const int model = pick_model(h);
-            const int nchunks = (model == MPC_MODEL_LANE || xtraj) ? 1 : n / MPC_CHUNK_MIN > MPC_MAX_CHUNKS ? MPC_MAX_CHUNKS
+            // (not for full SQP: its kernel runs 50x longer than the copy and every chunk would
+            //  wait for its own slowest instance — measured 351 -> 410 ms on 131072 instances)
+            const int nchunks = (model == MPC_MODEL_LANE || xtraj || h->spec.sqp_max_iter > 1) ? 1
+                                : n / MPC_CHUNK_MIN > MPC_MAX_CHUNKS ? MPC_MAX_CHUNKS
                                                                          : n / MPC_CHUNK_MIN > 1 ? n / MPC_CHUNK_MIN : 1;
             if (nchunks > 1) {
                 // Pipelined: chunk c + 1's inputs are copied (copy_stream) while chunk c is solved
