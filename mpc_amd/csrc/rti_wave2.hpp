@@ -105,6 +105,10 @@ struct Wave2 : Algebra {
         o.oz = a; o.one = b;
         return o;
     }
+    // acc + a0 b0 + a1 b1 + a2 b2 as one chain of fused multiply-adds
+    __device__ __forceinline__ static double fma3(double acc, double a0, double b0, double a1, double b1, double a2, double b2) {
+        return fma(a0, b0, fma(a1, b1, fma(a2, b2, acc)));
+    }
     __device__ __forceinline__ static double bf(const Stg& t, int j) { return j < 2 ? t.fbu : t.fbx; }
     __device__ __forceinline__ static bool has_bound(const Stg& t, int j) { return t.mid && (j < 2 || !t.is0); }
     __device__ __forceinline__ void con_cached(const Stg& t, int j, Con& q, const Opq& o) const {
@@ -570,8 +574,12 @@ struct Wave2 : Algebra {
         M3 Cm, Jm;
         Cm.m[0] = C[0]; Cm.m[1] = C[1]; Cm.m[2] = C[3]; Cm.m[3] = C[1]; Cm.m[4] = C[2]; Cm.m[5] = C[4]; Cm.m[6] = C[3]; Cm.m[7] = C[4]; Cm.m[8] = C[5];
         Jm.m[0] = J2[0]; Jm.m[1] = J2[1]; Jm.m[2] = J2[3]; Jm.m[3] = J2[1]; Jm.m[4] = J2[2]; Jm.m[5] = J2[4]; Jm.m[6] = J2[3]; Jm.m[7] = J2[4]; Jm.m[8] = J2[5];
+        // (sums that end in "+ accumulator" are written as one fused chain into the accumulator:
+        //  three instructions instead of multiply, two fused multiply-adds and an add)
         M3 Xm = m3_mul(Cm, Jm);
-        Xm.m[0] += 1.0; Xm.m[4] += 1.0; Xm.m[8] += 1.0;
+        Xm.m[0] = fma3(1.0, Cm.m[0], Jm.m[0], Cm.m[1], Jm.m[3], Cm.m[2], Jm.m[6]);
+        Xm.m[4] = fma3(1.0, Cm.m[3], Jm.m[1], Cm.m[4], Jm.m[4], Cm.m[5], Jm.m[7]);
+        Xm.m[8] = fma3(1.0, Cm.m[6], Jm.m[2], Cm.m[7], Jm.m[5], Cm.m[8], Jm.m[8]);
         M3 W;   // Xm^-1 (adjugate)
         const double c00 = Xm.m[4] * Xm.m[8] - Xm.m[5] * Xm.m[7];
         const double c01 = Xm.m[5] * Xm.m[6] - Xm.m[3] * Xm.m[8];
@@ -594,21 +602,21 @@ struct Wave2 : Algebra {
                 JW.m[3 * j + i] = JW.m[3 * i + j];
             }
         const M3 U = m3_mul(JW, A);
-        J[0] += A.m[0] * U.m[0] + A.m[3] * U.m[3] + A.m[6] * U.m[6];
-        J[1] += A.m[1] * U.m[0] + A.m[4] * U.m[3] + A.m[7] * U.m[6];
-        J[2] += A.m[1] * U.m[1] + A.m[4] * U.m[4] + A.m[7] * U.m[7];
-        J[3] += A.m[2] * U.m[0] + A.m[5] * U.m[3] + A.m[8] * U.m[6];
-        J[4] += A.m[2] * U.m[1] + A.m[5] * U.m[4] + A.m[8] * U.m[7];
-        J[5] += A.m[2] * U.m[2] + A.m[5] * U.m[5] + A.m[8] * U.m[8];
+        J[0] = fma3(J[0], A.m[0], U.m[0], A.m[3], U.m[3], A.m[6], U.m[6]);
+        J[1] = fma3(J[1], A.m[1], U.m[0], A.m[4], U.m[3], A.m[7], U.m[6]);
+        J[2] = fma3(J[2], A.m[1], U.m[1], A.m[4], U.m[4], A.m[7], U.m[7]);
+        J[3] = fma3(J[3], A.m[2], U.m[0], A.m[5], U.m[3], A.m[8], U.m[6]);
+        J[4] = fma3(J[4], A.m[2], U.m[1], A.m[5], U.m[4], A.m[8], U.m[7]);
+        J[5] = fma3(J[5], A.m[2], U.m[2], A.m[5], U.m[5], A.m[8], U.m[8]);
         if (more) {
             const M3 G = m3_mul(A2, W);
             const M3 T = m3_mul(G, Cm);
-            C[0] = C2[0] + (T.m[0] * A2.m[0] + T.m[1] * A2.m[1] + T.m[2] * A2.m[2]);
-            C[1] = C2[1] + (T.m[3] * A2.m[0] + T.m[4] * A2.m[1] + T.m[5] * A2.m[2]);
-            C[2] = C2[2] + (T.m[3] * A2.m[3] + T.m[4] * A2.m[4] + T.m[5] * A2.m[5]);
-            C[3] = C2[3] + (T.m[6] * A2.m[0] + T.m[7] * A2.m[1] + T.m[8] * A2.m[2]);
-            C[4] = C2[4] + (T.m[6] * A2.m[3] + T.m[7] * A2.m[4] + T.m[8] * A2.m[5]);
-            C[5] = C2[5] + (T.m[6] * A2.m[6] + T.m[7] * A2.m[7] + T.m[8] * A2.m[8]);
+            C[0] = fma3(C2[0], T.m[0], A2.m[0], T.m[1], A2.m[1], T.m[2], A2.m[2]);
+            C[1] = fma3(C2[1], T.m[3], A2.m[0], T.m[4], A2.m[1], T.m[5], A2.m[2]);
+            C[2] = fma3(C2[2], T.m[3], A2.m[3], T.m[4], A2.m[4], T.m[5], A2.m[5]);
+            C[3] = fma3(C2[3], T.m[6], A2.m[0], T.m[7], A2.m[1], T.m[8], A2.m[2]);
+            C[4] = fma3(C2[4], T.m[6], A2.m[3], T.m[7], A2.m[4], T.m[8], A2.m[5]);
+            C[5] = fma3(C2[5], T.m[6], A2.m[6], T.m[7], A2.m[7], T.m[8], A2.m[8]);
             A = m3_mul(G, A);
         }
     }
@@ -806,10 +814,9 @@ struct Wave2 : Algebra {
                 for (int i = 0; i < 9; ++i) Fz[e].m[i] = 0.0;
             }
         }
-        double stl[3], r[3];
-        m3_tmulv(Fz[0], sv[1], stl);
-        stl[0] += sv[0][0]; stl[1] += sv[0][1]; stl[2] += sv[0][2];
-        r[0] = stl[0]; r[1] = stl[1]; r[2] = stl[2];
+        double r[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = fma3(sv[0][i], Fz[0].m[i], sv[1][0], Fz[0].m[3 + i], sv[1][1], Fz[0].m[6 + i], sv[1][2]);
         x.next(r);
         if (k >= Nl) { r[0] = r[1] = r[2] = 0.0; }
         M3 M;
@@ -834,8 +841,8 @@ struct Wave2 : Algebra {
         }
         // r = p_{2k+2}; the odd stage's p_{2k+1} inside the lane
         double pm[3];
-        m3_tmulv(Fz[1], r, pm);
-        pm[0] += sv[1][0]; pm[1] += sv[1][1]; pm[2] += sv[1][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pm[i] = fma3(sv[1][i], Fz[1].m[i], r[0], Fz[1].m[3 + i], r[1], Fz[1].m[6 + i], r[2]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             Stg& t = s[e];
@@ -868,8 +875,8 @@ struct Wave2 : Algebra {
             Fz[e] = closed_loop_z(t, o);
         }
         double X[3];
-        m3_mulv(Fz[1], v[0], X);
-        X[0] += v[1][0]; X[1] += v[1][1]; X[2] += v[1][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) X[i] = fma3(v[1][i], Fz[1].m[3 * i], v[0][0], Fz[1].m[3 * i + 1], v[0][1], Fz[1].m[3 * i + 2], v[0][2]);
         int lvl = 0;
 #pragma unroll
         for (int d = 1; d < GW; d *= 2, ++lvl) {
@@ -877,17 +884,16 @@ struct Wave2 : Algebra {
             x.up(v1, d);
             const M3 Md = (!CACHE0 && lvl == 0) ? m3_mul(Fz[1], Fz[0]) : mc_load(lvl);
             if (!GUARD || (k >= d && k <= Nl)) {
-                double rr[3];
-                m3_mulv(Md, v1, rr);
-                X[0] += rr[0]; X[1] += rr[1]; X[2] += rr[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) X[i] = fma3(X[i], Md.m[3 * i], v1[0], Md.m[3 * i + 1], v1[1], Md.m[3 * i + 2], v1[2]);
             }
         }
         double dxa[3] = {X[0], X[1], X[2]};
         x.prev(dxa);
         if (k == 0) { dxa[0] = dxa[1] = dxa[2] = 0.0; }
         double dxb[3];
-        m3_mulv(Fz[0], dxa, dxb);
-        dxb[0] += v[0][0]; dxb[1] += v[0][1]; dxb[2] += v[0][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dxb[i] = fma3(v[0][i], Fz[0].m[3 * i], dxa[0], Fz[0].m[3 * i + 1], dxa[1], Fz[0].m[3 * i + 2], dxa[2]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const Stg& t = s[e];

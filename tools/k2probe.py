@@ -24,7 +24,7 @@ kern = body[:end]
 out = os.path.join("/tmp", "k2probe.hip")
 with open(out, "w") as f:
     f.write('#include <hip/hip_runtime.h>\n#include "consts.hpp"\n#include "rti_wave.hpp"\n#include "rti_wave2.hpp"\nusing namespace mpc;\n')
-    f.write(pol + "\n" + io + "\n" + kern + "\n")
+    f.write("#define MPC_STATUS_PENDING (-1)\n" + pol + "\n" + io + "\n" + kern + "\n")
     f.write("template __global__ void %s(Consts, Mem, int, int, WaveIO);\n" % inst)
 extra = sys.argv[2:]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", CS, "-Rpass-analysis=kernel-resource-usage",
