@@ -1010,7 +1010,7 @@ static int pick_model(const mpc_batch* h) {
     int model = h->model;
     if (model == MPC_MODEL_AUTO && model_env) {
         if (strcmp(model_env, "lane") == 0) model = MPC_MODEL_LANE;
-        else if (strcmp(model_env, "waveseq") == 0) model = MPC_MODEL_WAVE_SEQ;
+        else if (strcmp(model_env, "waveseq") == 0 || strcmp(model_env, "wave2seq") == 0) model = MPC_MODEL_WAVE_SEQ;
         else if (strcmp(model_env, "wave") == 0) model = MPC_MODEL_WAVE;
         else if (strcmp(model_env, "wave1") == 0) model = MPC_MODEL_WAVE1;
         else if (strcmp(model_env, "wave2") == 0) model = MPC_MODEL_WAVE2;
