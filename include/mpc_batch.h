@@ -109,7 +109,7 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
  * callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops,
  * harnesses that forbid allocation.  It is mpc_batch_solve_device's SQP_RTI step (same kernels,
  * same results) on capsules that live in a fixed array inside the library (one copy per GPU,
- * 35 MiB, held until the process ends) instead of in a handle:
+ * 36 MiB, held until the process ends) instead of in a handle:
  *   spec            as for mpc_batch_create; sqp_max_iter must be 1 (SQP_RTI)
  *   cold != 0       the first B capsules start from the all-zero iterate (a fresh handle);
  *   cold == 0       they start from the iterate the previous call ON THIS GPU left (a warm handle)
@@ -227,7 +227,9 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
  *            N <= 15 and full SQP with N <= 63;
  *   WAVE1    one stage per lane wherever it applies (N <= 63);   WAVE2: two stages per lane
  *            wherever it applies (N >= 16, SQP_RTI), whatever the batch size;
- *   WAVE_SEQ / WAVE2_SEQ  the same mappings with sequential recursions instead of the scans;
+ *   WAVE_SEQ / WAVE2_SEQ  (one and the same) two stages per lane with the sequential recursions
+ *            and HPIPM's iterative refinement — the kernel the scan models hand their declined
+ *            instances to (MPC_DIAG_SCAN_FALLBACK), here run on every instance; SQP_RTI only;
  *   LANE     one OCP per lane, IPM workspace in HBM (allocated on the first solve that uses it).
  * The environment variable MPC_MODEL=lane|wave|wave1|wave2|waveseq sets the default of handles
  * left on AUTO. */
