@@ -713,6 +713,36 @@ def test_latency_path_runs_the_list_kernel_only_when_needed(oracle):
     s.close()
 
 
+def test_chunked_host_solve_with_declined_instances():
+    """A host-pointer solve large enough to be pipelined in chunks (two here), on a workload where
+    the scan kernel declines about one instance in ten: every chunk has its own scan + list launch
+    pair on a slice of the handle's arrays and the list holds slice-relative indices.  Against the
+    sequential model on the same inputs: everything within 1e-9, and the declined instances — solved
+    by the very same sequential kernel — bit for bit."""
+    B = 32768 + 37
+    sp, wl = workload.make("mobile_robot", B)
+    x0, yref, yref_e = (a.copy() for a in wl.tick(0))
+    shift = x0[:, :2].copy()
+    x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+    sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sp.W), W_e=tuple(1e4 * w for w in sp.W_e))
+    out = {}
+    for model in ("auto", "wave2seq"):
+        s = capi.BatchSolver(sp, B)
+        s.set_model(model)
+        r = s.solve(x0, yref, yref_e)
+        _, u, _ = s.get(B, want_pi=False)
+        out[model] = (r, u, s.get_diag(B))
+        s.close()
+    (ra, ua, da), (rs, us, ds) = out["auto"], out["wave2seq"]
+    declined = (da & 4) != 0
+    assert 0.02 * B < declined.sum() < 0.5 * B and ((ds & 4) == 0).all()
+    for lo, hi in ((0, 16448), (16448, B)):     # both chunks took part
+        assert declined[lo:hi].any()
+    assert np.array_equal(ra["status"], rs["status"]) and np.array_equal(ra["qp_iter"], rs["qp_iter"])
+    assert np.abs(ua - us).max() < TOL_PATH and np.abs(ra["u0"] - rs["u0"]).max() < TOL_PATH
+    assert np.array_equal(ua[declined], us[declined]) and np.array_equal(ra["u0"][declined], rs["u0"][declined])
+
+
 def test_diag_is_clean_on_the_bench_workload():
     """None of the diagnostic bits (refinement performed / LQ switch may have fired / solved again by
     the sequential kernel) is raised on the headline workload."""
