@@ -103,7 +103,11 @@ def connect(backend, rank, world, device=None, log=None):
                 log(f"rank {rank}: nccl/RCCL unavailable ({e}); using gloo for barrier/all_reduce")
             if dist.is_initialized():
                 dist.destroy_process_group()
+            # a fresh rendezvous on the next port, hosted by rank 0 itself (under torchrun the
+            # agent hosts the store of MASTER_PORT only, and workers would wait for a server
+            # that nobody starts)
             os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
             backend = "gloo"
     init(backend, rank, world)
     return Ranks(rank, world, dist, backend, "cpu")
