@@ -314,6 +314,37 @@ def test_full_sqp_matches_oracle(oracle, name, B, model):
     solver.close()
 
 
+@pytest.mark.parametrize("N", [50, 80])
+def test_full_sqp_carries_on_in_the_list_kernel(oracle, N):
+    """Full SQP on the workload where the scan kernels decline instances (weights x 1e4, +-0.3 m
+    box): a declined QP ends the instance's loop in the scan kernel with the capsule at its last
+    accepted SQP iterate and the count of finished iterations in SQPITER; the sequential list kernel
+    carries on from there (k_wave<64, sqp> -> k_wave2<32, seq, sqp, list> at N = 50,
+    k_wave2<64, scan, sqp> -> k_wave2<64, seq, sqp, list> at N = 80).  Same status, same number of
+    QPs and the same trajectories as the oracle's SQP loop, for the declined instances too."""
+    B = 512
+    sp, wl = workload.make("mobile_robot", B, N=N, sqp_max_iter=12, nlp_tol=1e-5)
+    x0, yref, yref_e = (a.copy() for a in wl.tick(0))
+    shift = x0[:, :2].copy()
+    x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+    sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sp.W), W_e=tuple(1e4 * w for w in sp.W_e))
+    ro = oracle.sqp_batch(sp, x0, yref, yref_e)
+    s = capi.BatchSolver(sp, B)
+    rg = s.solve(x0, yref, yref_e)
+    sit, res = s.get_sqp(B)
+    xg, ug, _ = s.get(B)
+    dg = s.get_diag(B)
+    declined = (dg & 4) != 0
+    assert declined.sum() >= 5, int(declined.sum())
+    assert np.array_equal(ro["status"], rg["status"])
+    same = ro["sqp_iter"] == sit
+    assert same.mean() >= 0.98 and same[declined].mean() >= 0.9, (same.mean(), same[declined].mean())
+    assert np.abs(ro["utraj"] - ug)[same].max() < TOL_HARD and np.abs(ro["xtraj"] - xg)[same].max() < TOL_HARD
+    assert np.abs(ro["utraj"] - ug)[same & declined].max() < TOL_HARD
+    assert np.array_equal(rg["u0"], ug[:, 0])
+    s.close()
+
+
 def test_device_closed_loop_matches_per_vehicle_optimizers(oracle):
     """mpc_batch_track_* (window selection + reference packing + solve + plant step,
     all on the device) against B independent host-side `Optimizer` mirrors running on the oracle:
