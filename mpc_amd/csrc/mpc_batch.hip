@@ -845,7 +845,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_track_advance(Consts c, Mem m, Tra
 // ------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------
-#define MPC_MAX_CHUNKS 4
+#define MPC_MAX_CHUNKS 3
 #define MPC_CHUNK_MIN 16384   // instances: below two chunks of this size a solve is not split
 struct Shard {
     int device = -1;
@@ -855,7 +855,8 @@ struct Shard {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ph[2] = {};   // around the dominant solve kernel of the last solve
-    // host-pointer solves of large batches are pipelined in chunks: the inputs of chunk c + 1 travel
+    // host-pointer solves of large batches are pipelined in up to three chunks (65536 x N = 50 from
+    // pinned arrays: 1 chunk 8.9 ms, 2: 8.0, 3: 7.9, 4: 8.1, 8: 9.1 — every chunk waits for its slowest wavefront): the inputs of chunk c + 1 travel
     // on copy_stream while the kernels of chunk c run on `stream` (created on first use)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_chunk[MPC_MAX_CHUNKS] = {};
