@@ -193,41 +193,52 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         return;
     }
     // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update;
-    //      the whole loop runs inside the kernel, one OCP per group, no host round trip ----
+    //      the whole loop runs inside the kernel, one OCP per group, no host round trip.
+    //      As in k_wave2 the iterate (x, u, pi, lam) is not carried in registers across the QP: every
+    //      SQP iteration reads it from the capsule and an accepted QP writes its solution back; every
+    //      lane linearises and cold-starts whether its OCP still runs or not (a finished group works
+    //      on its final iterate and writes nothing), so the solver state is dead across the outer
+    //      loop.  A failed or declined QP writes nothing: the capsule keeps the last accepted iterate
+    //      (which is where the sequential list kernel carries on after a decline). ----
     double* lk = m.lam + ((size_t)ic * (N + 1) + kcl) * 8;   // this lane's bound multipliers
-    double pin[3], lamn[8], res[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 3; ++q) pin[q] = (on && k < N) ? ck[C_PI + q] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) lamn[q] = (on && k < N) ? lk[q] : 0.0;
+    double res[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool midl = on && k < N;
     bool running = inst;
     bool redo = false;
     int sqp_it = 0, qp_it = 0, diag = 0;
     status = 2;   // MAXITER unless a residual check passes
     for (;;) {
         if (running && sqp_it >= sqp_max_iter) running = false;   // MAXITER: no check after the last QP
-        if (running) {
-            double xn[3];
+        if (!w.x.any(running)) break;
+        {
+            double pin[3], lamn[8], xn[3], rr[4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xi[q] = on ? ck[C_X + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ui[q] = midl ? ck[C_U + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pin[q] = midl ? ck[C_PI + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lamn[q] = midl ? lk[q] : 0.0;
             w.linearize(xi, ui, xn);
-            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, res);
-            if (res[0] < c.nlp_tol && res[1] < c.nlp_tol && res[2] < c.nlp_tol && res[3] < c.nlp_tol) {
-                status = 0;
-                running = false;
+            w.nlp_residuals(xi, ui, x0b, xn, pin, lamn, rr);
+            if (running) {
+                res[0] = rr[0]; res[1] = rr[1]; res[2] = rr[2]; res[3] = rr[3];
+                if (rr[0] < c.nlp_tol && rr[1] < c.nlp_tol && rr[2] < c.nlp_tol && rr[3] < c.nlp_tol) {
+                    status = 0;
+                    running = false;
+                }
             }
         }
         if (!w.x.any(running)) break;
-        if (running) {
-            w.cold_start(xi, ui, x0b);
-            w.begin(s);
-        }
+        w.cold_start(xi, ui, x0b);
+        w.begin(s);
         for (;;) {
             const bool go = running && w.cont(s);
             if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
         if (SCAN && running && s.declined) {
-            // the last accepted iterate goes to the capsule below and the sequential kernel carries
-            // on from there (k_wave2<.., SQP, LIST>), with the count of finished SQP iterations
             redo = true;
             running = false;
         }
@@ -241,40 +252,36 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
             diag |= s.diag;
             ++sqp_it;
             if (hs == 0 || hs == 1) {
-                ui[0] = w.z[0]; ui[1] = w.z[1];
+                if (on) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { xi[q] = w.z[2 + q]; pin[q] = w.pi[q]; }
+                    for (int q = 0; q < 3; ++q) ck[C_X + q] = w.z[2 + q];
+                    if (k < N) {
+                        ck[C_U + 0] = w.z[0]; ck[C_U + 1] = w.z[1];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) lamn[q] = w.has_bound(q & 3) ? w.bn.lam[q] : 0.0;
+                        for (int q = 0; q < 3; ++q) ck[C_PI + q] = w.pi[q];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) lk[q] = w.has_bound(q & 3) ? w.bn.lam[q] : 0.0;
+                    }
+                }
             } else {
                 status = 4;
                 running = false;
             }
         }
     }
-    if (!on) return;
-    if (k == 0 && redo) {
+    if (!on || k != 0) return;
+    if (redo) {
         m.SQPITER[i] = sqp_it;
         m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
         if (io.status) io.status[i] = MPC_STATUS_PENDING;
+        return;
     }
-    if (k == 0 && !redo) {
-        m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
+    m.QPITER[i] = qp_it; m.DIAG[i] = diag | w.wdiag; m.STATUS[i] = status; m.SQPITER[i] = sqp_it; m.ACTIVE[i] = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
-        if (io.status) io.status[i] = status;
-        if (io.qp_iter) io.qp_iter[i] = qp_it;
-        io.u0[2 * i] = ui[0]; io.u0[2 * i + 1] = ui[1];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) ck[C_X + q] = xi[q];
-    if (k < N) {
-        ck[C_U + 0] = ui[0]; ck[C_U + 1] = ui[1];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) ck[C_PI + q] = pin[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lk[q] = lamn[q];
-    }
+    for (int q = 0; q < 4; ++q) m.NLPRES[4 * i + q] = res[q];
+    if (io.status) io.status[i] = status;
+    if (io.qp_iter) io.qp_iter[i] = qp_it;
+    io.u0[2 * i] = ck[C_U + 0]; io.u0[2 * i + 1] = ck[C_U + 1];   // this lane's own line of the capsule
 }
 
 // The same step with TWO stages per lane (rti_wave2.hpp): lane k of a GW-lane group owns stages 2k

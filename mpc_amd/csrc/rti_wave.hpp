@@ -316,15 +316,15 @@ struct Wave : Algebra {
             double tl = z[j] - c.lb[j];
             double tu = c.ub[j] - z[j];
             double zj = z[j];
-            if (tl < c.thr0) {
-                if (tu < c.thr0) { zj = 0.5 * (c.lb[j] + c.ub[j]); tl = c.thr0; tu = c.thr0; }
-                else { tl = c.thr0; zj = c.lb[j] + c.thr0; }
-            } else if (tu < c.thr0) { tu = c.thr0; zj = c.ub[j] - c.thr0; }
+            if (tl < MPC_IPM_THR0) {
+                if (tu < MPC_IPM_THR0) { zj = 0.5 * (c.lb[j] + c.ub[j]); tl = MPC_IPM_THR0; tu = MPC_IPM_THR0; }
+                else { tl = MPC_IPM_THR0; zj = c.lb[j] + MPC_IPM_THR0; }
+            } else if (tu < MPC_IPM_THR0) { tu = MPC_IPM_THR0; zj = c.ub[j] - MPC_IPM_THR0; }
             if (has_bound(j)) {
                 z[j] = zj;
                 bn.t[j] = tl; bn.t[4 + j] = tu;
                 ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
-                bn.lam[j] = c.mu0 * ti[j]; bn.lam[4 + j] = c.mu0 * ti[4 + j];
+                bn.lam[j] = MPC_IPM_MU0 * ti[j]; bn.lam[4 + j] = MPC_IPM_MU0 * ti[4 + j];
             } else {
                 bn.t[j] = 1.0; bn.t[4 + j] = 1.0;
                 bn.lam[j] = 0.0; bn.lam[4 + j] = 0.0;
@@ -369,9 +369,9 @@ struct Wave : Algebra {
             Con q;
             con_cached(j, q);
             rg[j] += q.lam_u - q.lam_l;
-            viol = viol || (has_bound(j) && (fabs(q.rd_l) > c.res_d_max || fabs(q.rd_u) > c.res_d_max ||
-                                             fabs(fabs(q.rm_l) - c.tau_min) > c.res_m_max ||
-                                             fabs(fabs(q.rm_u) - c.tau_min) > c.res_m_max));
+            viol = viol || (has_bound(j) && (fabs(q.rd_l) > MPC_IPM_RES_D_MAX || fabs(q.rd_u) > MPC_IPM_RES_D_MAX ||
+                                             fabs(fabs(q.rm_l) - MPC_IPM_TAU_MIN) > MPC_IPM_RES_M_MAX ||
+                                             fabs(fabs(q.rm_u) - MPC_IPM_TAU_MIN) > MPC_IPM_RES_M_MAX));
             ps += q.rm_l;
             ps += q.rm_u;
         }
@@ -392,7 +392,7 @@ struct Wave : Algebra {
         // HPIPM tests the four inf-norms against their tolerances; "max over lanes > tol" is "any
         // lane > tol" (|m - tau_min| > tol is monotone in m for m >= tau_min and false below), so
         // the four max-reductions collapse into one ballot.  Only mu needs a real reduction.
-        open = x.gany(pg > c.res_g_max || pb > c.res_b_max || viol);
+        open = x.gany(pg > MPC_IPM_RES_G_MAX || pb > MPC_IPM_RES_B_MAX || viol);
         double ns[1] = {ps};
         x.rsum(ns);
         musum = ns[0];
@@ -431,8 +431,8 @@ struct Wave : Algebra {
     //     owns the stage computes, P and p move one lane down per step.
     __device__ __forceinline__ void factor_seq(const double Gam[4], const double gam[4]) {
         Sym3 Po;
-        Po.p00 = c.we[0] + c.reg_prim; Po.p10 = 0.0; Po.p11 = c.we[1] + c.reg_prim;
-        Po.p20 = 0.0; Po.p21 = 0.0; Po.p22 = c.we[2] + c.reg_prim;
+        Po.p00 = c.wer[0]; Po.p10 = 0.0; Po.p11 = c.wer[1];
+        Po.p20 = 0.0; Po.p21 = 0.0; Po.p22 = c.wer[2];
         double po0 = rg[2], po1 = rg[3], po2 = rg[4];   // meaningful in lane N
         for (int kc = N - 1; kc >= 0; --kc) {
             double sh[9] = {Po.p00, Po.p10, Po.p11, Po.p20, Po.p21, Po.p22, po0, po1, po2};
@@ -457,12 +457,12 @@ struct Wave : Algebra {
                     const double S02 = P.p00 * a + P.p10 * b + P.p20;
                     const double S12 = P.p10 * a + P.p11 * b + P.p21;
                     const double S22 = P.p20 * a + P.p21 * b + P.p22;
-                    const double Hxx00 = (c.wg[2] + c.reg_prim) + Gam[2] + P.p00;
+                    const double Hxx00 = c.wgr[2] + Gam[2] + P.p00;
                     const double Hxx10 = P.p10;
-                    const double Hxx11 = (c.wg[3] + c.reg_prim) + Gam[3] + P.p11;
+                    const double Hxx11 = c.wgr[3] + Gam[3] + P.p11;
                     const double Hxx20 = a * P.p00 + b * P.p10 + P.p20;
                     const double Hxx21 = a * P.p10 + b * P.p11 + P.p21;
-                    const double Hxx22 = (c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22);
+                    const double Hxx22 = c.wgr[4] + (a * S02 + b * S12 + S22);
                     Po.p00 = Hxx00 + (g.M00 * g.K00 + g.M10 * g.K10);
                     Po.p10 = Hxx10 + (g.M01 * g.K00 + g.M11 * g.K10);
                     Po.p11 = Hxx11 + (g.M01 * g.K01 + g.M11 * g.K11);
@@ -615,7 +615,7 @@ struct Wave : Algebra {
         double C[6], J[6];   // symmetric: 00, 10, 11, 20, 21, 22
         if (mid) {
             A.m[0] = 1.0; A.m[1] = 0.0; A.m[2] = ab.a; A.m[3] = 0.0; A.m[4] = 1.0; A.m[5] = ab.b; A.m[6] = 0.0; A.m[7] = 0.0; A.m[8] = 1.0;
-            const double r0 = rcp((c.wg[0] + c.reg_prim) + Gam[0]), r1 = rcp((c.wg[1] + c.reg_prim) + Gam[1]);
+            const double r0 = rcp(c.wgr[0] + Gam[0]), r1 = rcp(c.wgr[1] + Gam[1]);
             const double b00 = ab.B00 * r0, b10 = ab.B10 * r0, b20 = ab.B20 * r0;
             const double b01 = ab.B01 * r1, b11 = ab.B11 * r1, b21 = ab.B21 * r1;
             C[0] = b00 * ab.B00 + b01 * ab.B01;
@@ -624,14 +624,14 @@ struct Wave : Algebra {
             C[3] = b20 * ab.B00 + b21 * ab.B01;
             C[4] = b20 * ab.B10 + b21 * ab.B11;
             C[5] = b20 * ab.B20 + b21 * ab.B21;
-            J[0] = (c.wg[2] + c.reg_prim) + Gam[2]; J[1] = 0.0; J[2] = (c.wg[3] + c.reg_prim) + Gam[3];
-            J[3] = 0.0; J[4] = 0.0; J[5] = c.wg[4] + c.reg_prim;
+            J[0] = c.wgr[2] + Gam[2]; J[1] = 0.0; J[2] = c.wgr[3] + Gam[3];
+            J[3] = 0.0; J[4] = 0.0; J[5] = c.wgr[4];
         } else {
 #pragma unroll
             for (int i = 0; i < 9; ++i) A.m[i] = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) { C[i] = 0.0; J[i] = 0.0; }
-            J[0] = c.we[0] + c.reg_prim; J[2] = c.we[1] + c.reg_prim; J[5] = c.we[2] + c.reg_prim;
+            J[0] = c.wer[0]; J[2] = c.wer[1]; J[5] = c.wer[2];
         }
         // --- suffix scan, first level (distance 1) on the structured single-stage elements:
         //     A = e I + a E02 + b E12 (e = 1, or 0 from stage N on), J diagonal.  The same
@@ -809,12 +809,12 @@ struct Wave : Algebra {
             const double S02 = P.p00 * a + P.p10 * b + P.p20;
             const double S12 = P.p10 * a + P.p11 * b + P.p21;
             const double S22 = P.p20 * a + P.p21 * b + P.p22;
-            const double Q00 = ((c.wg[2] + c.reg_prim) + Gam[2] + P.p00) + (g.M00 * g.K00 + g.M10 * g.K10);
+            const double Q00 = (c.wgr[2] + Gam[2] + P.p00) + (g.M00 * g.K00 + g.M10 * g.K10);
             const double Q10 = P.p10 + (g.M01 * g.K00 + g.M11 * g.K10);
-            const double Q11 = ((c.wg[3] + c.reg_prim) + Gam[3] + P.p11) + (g.M01 * g.K01 + g.M11 * g.K11);
+            const double Q11 = (c.wgr[3] + Gam[3] + P.p11) + (g.M01 * g.K01 + g.M11 * g.K11);
             const double Q20 = (a * P.p00 + b * P.p10 + P.p20) + (g.X02 * g.K00 + g.X12 * g.K10);
             const double Q21 = (a * P.p10 + b * P.p11 + P.p21) + (g.X02 * g.K01 + g.X12 * g.K11);
-            const double Q22 = ((c.wg[4] + c.reg_prim) + (a * S02 + b * S12 + S22)) + (g.X02 * g.K02 + g.X12 * g.K12);
+            const double Q22 = (c.wgr[4] + (a * S02 + b * S12 + S22)) + (g.X02 * g.K02 + g.X12 * g.K12);
             double err = fmax(fmax(fabs(Q00 - J[0]), fabs(Q10 - J[1])), fmax(fabs(Q11 - J[2]), fabs(Q20 - J[3])));
             err = fmax(err, fmax(fabs(Q21 - J[4]), fabs(Q22 - J[5])));
             const double scale = fmax(fmax(fabs(J[0]), fabs(J[2])), fabs(J[5]));
@@ -1082,9 +1082,9 @@ struct Wave : Algebra {
         x.rsum(as);
         o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
         // the linear system's residual is only ever compared with thresholds: ballots
-        o.lin_itref = FINAL ? x.gany(!(lin_g < c.itref_tol_g)) : false;
-        o.lin_lq = FINAL ? x.gany(!(lin_g < c.lq_tol)) : false;
-        o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
+        o.lin_itref = FINAL ? x.gany(!(lin_g < MPC_IPM_RES_G_MAX)) : false;
+        o.lin_lq = FINAL ? x.gany(!(lin_g < MPC_IPM_LQ_SWITCH_TOL)) : false;
+        o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < 1e-8 /* kScanTolLin, consts.hpp */)) : false;
         o.redo_centering = false;
         o.accepted = false;
         if (FINAL) {
@@ -1100,13 +1100,13 @@ struct Wave : Algebra {
                 if (a_upd < 1.0) a_upd = a_upd * ((1.0 - a_upd) * MPC_IPM_STEP_SCALE_LO + a_upd * MPC_IPM_STEP_SCALE_HI);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const double aj = a_upd * bf(j), lmin = c.lam_min * bf(j);   // no bound: lam stays 0, t stays 1
+                    const double aj = a_upd * bf(j), lmin = MPC_IPM_LAM_MIN * bf(j);   // no bound: lam stays 0, t stays 1
                     double ll = bn.lam[j] + aj * st[j].dl_l, lu = bn.lam[4 + j] + aj * st[j].dl_u;
                     double tl = bn.t[j] + aj * st[j].dt_l, tu = bn.t[4 + j] + aj * st[j].dt_u;
                     if (ll < lmin) ll = lmin;
                     if (lu < lmin) lu = lmin;
-                    if (tl < c.t_min) tl = c.t_min;
-                    if (tu < c.t_min) tu = c.t_min;
+                    if (tl < MPC_IPM_T_MIN) tl = MPC_IPM_T_MIN;
+                    if (tu < MPC_IPM_T_MIN) tu = MPC_IPM_T_MIN;
                     bn.lam[j] = ll; bn.lam[4 + j] = lu; bn.t[j] = tl; bn.t[4 + j] = tu;
                     ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
                 }
@@ -1119,7 +1119,7 @@ struct Wave : Algebra {
     }
 
     // ---- the RTI step (Lane::begin / cont / iterate) ----
-    __device__ __forceinline__ double nc_inv() const { return 1.0 / (4 + 8 * (c.N - 1)); }
+    __device__ __forceinline__ double nc_inv() const { return c.nc_inv; }
     __device__ __forceinline__ void begin(State& s) {
         bu(s.musum, s.open);
         s.mu = s.musum * nc_inv();
@@ -1129,7 +1129,7 @@ struct Wave : Algebra {
         s.declined = false;
     }
     __device__ __forceinline__ bool cont(const State& s) const {
-        return s.kk < c.iter_max && s.alpha > c.alpha_min && s.open && !s.declined;
+        return s.kk < c.iter_max && s.alpha > MPC_IPM_ALPHA_MIN && s.open && !s.declined;
     }
     // One IPM iteration.  SCAN build: the stationarity and dynamics rows of the linearised KKT
     // system (lin_g; what HPIPM's refinement loop tests against 1e-6 / 1e-8) are checked against
@@ -1150,7 +1150,7 @@ struct Wave : Algebra {
         const double tmp = mu_aff0 / s.mu;
         const double sigma = tmp * tmp * tmp;
         sigma_mu = sigma * s.mu;
-        if (!(sigma_mu > c.tau_min)) sigma_mu = c.tau_min;
+        if (!(sigma_mu > MPC_IPM_TAU_MIN)) sigma_mu = MPC_IPM_TAU_MIN;
         // corrector; conditional predictor-corrector: if mu would grow, redo it as pure centering
 #pragma nounroll
         for (;;) {
