@@ -243,12 +243,25 @@ struct Wave : Algebra {
     }
     __device__ __forceinline__ bool has_bound(int j) const { return mid && (j < 2 || !is0); }
     // Algebra::con_make with the cached reciprocals
-    __device__ __forceinline__ void con_cached(int j, Con& q) const {
+    // Phase-local opaque constants 0.0 and 1.0 (see rti_wave2.hpp opq()): every phase recomputes
+    // these cheap per-bound quantities; written with constants the compiler cannot see through, the
+    // recomputations are not merged across phases (which would keep them live through the scans).
+    // Same bits: fma(t, 1.0, lb) = lb + t, fma(lam, t, 0.0) = lam * t.
+    struct Opq { double oz, one; };
+    __device__ __forceinline__ static Opq opq() {
+        Opq o;
+        double a = 0.0, b = 1.0;
+        asm volatile("" : "+v"(a));
+        asm volatile("" : "+v"(b));
+        o.oz = a; o.one = b;
+        return o;
+    }
+    __device__ __forceinline__ void con_cached(int j, Con& q, const Opq& o) const {
         q.lam_l = bn.lam[j]; q.lam_u = bn.lam[4 + j]; q.t_l = bn.t[j]; q.t_u = bn.t[4 + j];
-        q.rd_l = c.lb[j] + q.t_l - z[j];
-        q.rd_u = q.t_u + z[j] - c.ub[j];
-        q.rm_l = q.lam_l * q.t_l;
-        q.rm_u = q.lam_u * q.t_u;
+        q.rd_l = fma(q.t_l, o.one, c.lb[j]) - z[j];
+        q.rd_u = fma(q.t_u, o.one, z[j]) - c.ub[j];
+        q.rm_l = fma(q.lam_l, q.t_l, o.oz);
+        q.rm_u = fma(q.lam_u, q.t_u, o.oz);
         q.ti_l = ti[j];
         q.ti_u = ti[4 + j];
     }
@@ -320,16 +333,15 @@ struct Wave : Algebra {
                 if (tu < MPC_IPM_THR0) { zj = 0.5 * (c.lb[j] + c.ub[j]); tl = MPC_IPM_THR0; tu = MPC_IPM_THR0; }
                 else { tl = MPC_IPM_THR0; zj = c.lb[j] + MPC_IPM_THR0; }
             } else if (tu < MPC_IPM_THR0) { tu = MPC_IPM_THR0; zj = c.ub[j] - MPC_IPM_THR0; }
-            if (has_bound(j)) {
-                z[j] = zj;
-                bn.t[j] = tl; bn.t[4 + j] = tu;
-                ti[j] = rcp(tl); ti[4 + j] = rcp(tu);
-                bn.lam[j] = MPC_IPM_MU0 * ti[j]; bn.lam[4 + j] = MPC_IPM_MU0 * ti[4 + j];
-            } else {
-                bn.t[j] = 1.0; bn.t[4 + j] = 1.0;
-                bn.lam[j] = 0.0; bn.lam[4 + j] = 0.0;
-                ti[j] = 1.0; ti[4 + j] = 1.0;
-            }
+            // every member is written once, through selects: stores to the same member in both arms
+            // of a branch are sunk into one store through a phi ADDRESS, which keeps the whole
+            // array in scratch
+            const bool hb = has_bound(j);
+            const double il = rcp(tl), iu = rcp(tu);
+            z[j] = hb ? zj : z[j];
+            bn.t[j] = hb ? tl : 1.0; bn.t[4 + j] = hb ? tu : 1.0;
+            ti[j] = hb ? il : 1.0; ti[4 + j] = hb ? iu : 1.0;
+            bn.lam[j] = hb ? MPC_IPM_MU0 * il : 0.0; bn.lam[4 + j] = hb ? MPC_IPM_MU0 * iu : 0.0;
         }
         pi[0] = pi[1] = pi[2] = 0.0;
 #pragma unroll
@@ -364,10 +376,11 @@ struct Wave : Algebra {
         // The norms themselves are only compared with tolerances ("max > tol" = "any > tol").
         double pg = 0.0, pb = 0.0, ps = 0.0;
         bool viol = false;
+const Opq oq_ = opq();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_cached(j, q);
+            con_cached(j, q, oq_);
             rg[j] += q.lam_u - q.lam_l;
             viol = viol || (has_bound(j) && (fabs(q.rd_l) > MPC_IPM_RES_D_MAX || fabs(q.rd_u) > MPC_IPM_RES_D_MAX ||
                                              fabs(fabs(q.rm_l) - MPC_IPM_TAU_MIN) > MPC_IPM_RES_M_MAX ||
@@ -402,10 +415,11 @@ struct Wave : Algebra {
     // and the Riccati factorisation with the affine right-hand side: the head of an IPM iteration.
     __device__ __forceinline__ void factor_now() {
         double Gam[4], gam[4];
+const Opq oq_ = opq();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_cached(j, q);
+            con_cached(j, q, oq_);
             Gam[j] = con_Gamma(q);
             gam[j] = con_gamma(q);
         }
@@ -918,10 +932,11 @@ struct Wave : Algebra {
     // ---- BW: corrected complementarity -> new right-hand side, backward.  Lane::sweep_bw.
     __device__ __forceinline__ void bw(int mode, double sigma_mu) {
         double gam[4];
+const Opq oq_ = opq();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_cached(j, q);
+            con_cached(j, q, oq_);
             con_correct(q, mode, dza[j], sigma_mu * bf(j));
             gam[j] = con_gamma(q);   // exactly 0 without a bound
         }
@@ -1012,10 +1027,11 @@ struct Wave : Algebra {
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
         double dlam_net[4] = {0.0, 0.0, 0.0, 0.0};
         Step st[4];
+const Opq oq_ = opq();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Con q;
-            con_cached(j, q);
+            con_cached(j, q, oq_);
             if (FINAL) con_correct(q, mode, dza[j], sigma_mu * bf(j));
             Step s;
             con_step(q, dl[j], s);
