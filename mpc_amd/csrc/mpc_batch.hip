@@ -1164,13 +1164,15 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
             MPC_LAUNCH_LIST();
         } else MPC_LAUNCH_WAVE2(64);
     } else if (one_stage_per_lane || sqp || N + 1 <= 16 ||
-               (!two_stages_per_lane && n / (N + 1 <= 32 ? 2 : 1) <= 4 * MPC_SIMD_SLOTS)) {
+               (!two_stages_per_lane && n <= 16 * MPC_SIMD_SLOTS)) {
         // One stage per lane: N + 1 <= 16 fills a 16-lane group as it is (four OCPs per wavefront
         // either way); full SQP keeps one OCP per wavefront where it can — OCPs that share a
-        // wavefront wait for each other, and SQP iteration counts spread from 1 to 100; and small
-        // batches (the batch = 1 control loop up to four rounds of wavefronts over the chip's 1024
-        // SIMDs) are latency-bound: a wavefront that carries half as many stages per lane finishes
-        // an IPM iteration in 60 % of the time.
+        // wavefront wait for each other, and SQP iteration counts spread from 1 to 100; and batches
+        // up to 16384 instances (from the batch = 1 control loop to a few rounds of wavefronts over
+        // the chip's 1024 SIMDs): a wavefront that carries half as many stages per lane finishes an
+        // IPM iteration in 60 % of the time, and nothing waits for a partner OCP.  Measured kernel
+        // time one stage / two stages per lane at N = 50: 1024 instances 0.26 / 0.45 ms, 4096:
+        // 0.59 / 0.72, 8192: 1.00 / 1.08, 16384: 1.80 / 1.81, 65536: 5.95 / 5.60 (N = 25 and 40 alike).
         if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
         else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
         else MPC_LAUNCH_WAVE(XWave<64>);
