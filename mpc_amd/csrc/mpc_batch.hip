@@ -123,9 +123,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     const int kcl = k <= N ? k : N;
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     X xpol = make_policy<X>(l);
-    // product cache of the scans (rti_wave.hpp build_products): [level][pair][lane] double2
-    __shared__ mc_d2 mc_lds[(X::MCACHE && SCAN) ? X::MC_LEVELS * MPC_MC_PAIRS * 64 : 1];
-    Wave<X, SCAN> w(c, k, xpol, mc_lds + (l & 63));
+    Wave<X, SCAN> w(c, k, xpol);   // (no LDS: the product cache of the scans lives in registers, rti_wave.hpp Mc)
     if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter (Mem::REDO)
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];

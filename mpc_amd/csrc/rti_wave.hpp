@@ -119,8 +119,9 @@ __device__ __forceinline__ void m3_tmulv(const M3& a, const double v[3], double 
 #pragma unroll
     for (int i = 0; i < 3; ++i) r[i] = a.m[i] * v[0] + a.m[3 + i] * v[1] + a.m[6 + i] * v[2];
 }
-// LDS cache of the closed-loop products: [level][5 pairs][64 lanes] of double2 (ds_*_b128,
-// lane-contiguous); every lane only ever reads what it wrote itself, so no barrier is involved.
+// LDS cache of the closed-loop products of rti_wave2.hpp (and its parked per-stage state):
+// [slot][64 lanes] of double2 (ds_*_b128, lane-contiguous); every lane only ever reads what it
+// wrote itself, so no barrier is involved.
 typedef double mc_d2 __attribute__((ext_vector_type(2)));
 #define MPC_MC_PAIRS 5
 struct OpMax {
@@ -200,7 +201,6 @@ struct Wave : Algebra {
     double ti[8];                // 1 / t of the current slacks (same bits as recomputing it in every pass)
     int wdiag = 0;               // MPC_DIAG_* bits raised inside the sweeps
     static constexpr bool seq_now = false;   // (the in-kernel sequential redo of an iteration is gone: see iterate)
-    mc_d2* mc = nullptr;         // this lane's column of the product cache (X::MCACHE)
     // 1.0 where this stage has input bounds (k < N) / state bounds (0 < k < N), else 0.0.  Entries
     // without a bound carry lam = 0, t = 1; scaling sigma*mu, the step length and the lam clamp by
     // these factors keeps them there and makes every contribution of such an entry an exact zero,
@@ -215,32 +215,21 @@ struct Wave : Algebra {
         bool declined;  // SCAN: the scan step of this iteration was not accurate enough (see iterate)
     };
 
-    __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_, mc_d2* mc_ = nullptr)
-        : Algebra(c_), x(x_), k(stage), N(c_.N), mc(mc_) {
+    __device__ __forceinline__ Wave(const Consts& c_, int stage, const X& x_)
+        : Algebra(c_), x(x_), k(stage), N(c_.N) {
         act = k <= N; mid = k < N; isN = k == N; is0 = k == 0;
         fbu = mid ? 1.0 : 0.0;
         fbx = (mid && !is0) ? 1.0 : 0.0;
     }
     __device__ __forceinline__ double bf(int j) const { return j < 2 ? fbu : fbx; }
-    __device__ __forceinline__ void mc_store(int level, const M3& M) const {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            mc_d2 v; v.x = M.m[2 * q]; v.y = M.m[2 * q + 1];
-            mc[(level * MPC_MC_PAIRS + q) * 64] = v;
-        }
-        mc_d2 v; v.x = M.m[8]; v.y = 0.0;
-        mc[(level * MPC_MC_PAIRS + 4) * 64] = v;
-    }
-    __device__ __forceinline__ M3 mc_load(int level) const {
-        M3 M;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const mc_d2 v = mc[(level * MPC_MC_PAIRS + q) * 64];
-            M.m[2 * q] = v.x; M.m[2 * q + 1] = v.y;
-        }
-        M.m[8] = mc[(level * MPC_MC_PAIRS + 4) * 64].x;
-        return M;
-    }
+    // The cached products M^(d)_k (build_products / suffix_cached) live in registers: the kernel has
+    // ~115 accumulation registers to spare, the compiler parks the 6 x 9 doubles there, and a scan
+    // level fetches its matrix with 18 register copies instead of 5 LDS reads — measured against
+    // the LDS cache of round 1: 65536 x N = 50 5.95 -> 5.82 ms, full SQP 299 -> 291 ms (the LDS
+    // pipe is shared by the four wavefronts of a CU and these kernels wait on it), batch = 1 the same.
+    M3 Mc[X::MC_LEVELS];
+    __device__ __forceinline__ void mc_store(int level, const M3& M) { Mc[level] = M; }
+    __device__ __forceinline__ M3 mc_load(int level) const { return Mc[level]; }
     __device__ __forceinline__ bool has_bound(int j) const { return mid && (j < 2 || !is0); }
     // Algebra::con_make with the cached reciprocals
     // Phase-local opaque constants 0.0 and 1.0 (see rti_wave2.hpp opq()): every phase recomputes
@@ -565,7 +554,8 @@ const Opq oq_ = opq();
 
     // ---- X::MCACHE: the products of the closed-loop transitions are shared by all four vector
     //      recursions of an IPM iteration (predictor and corrector, backward and forward), so
-    //      they are formed once per factorisation and parked in LDS:
+    //      they are formed once per factorisation and kept (in registers here: Mc; in LDS in
+    //      rti_wave2.hpp):
     //          M^(d)_k = Phi_k Phi_{k-1} .. Phi_{k-d+1},   d = 1, 2, .., GW/2,
     //      with Phi_0 := 0 (dx_0 = 0) and Phi_k := 0 from stage N on.  The forward scan pulls
     //      dx from lane k-d and applies its own M^(d)_k; the backward scan runs on
@@ -577,7 +567,7 @@ const Opq oq_ = opq();
     // BUILD: the first backward scan after a factorisation also forms and stores the products
     // (the two shuffles of a level travel together: one LDS round trip instead of two).
     template <bool BUILD>
-    __device__ __forceinline__ void suffix_cached(const double s[3], double (&r)[3]) const {
+    __device__ __forceinline__ void suffix_cached(const double s[3], double (&r)[3]) {
         r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
         x.next(r);
         if (!mid) { r[0] = r[1] = r[2] = 0.0; }
