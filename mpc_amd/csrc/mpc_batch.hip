@@ -348,12 +348,24 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
             w.linearize(e, xi[e], ui[e], xn);
             w.cold_start(e, xi[e], ui[e], x0b);
         }
+#ifdef MPC_PHASE_CLOCK
+        const long long tk0 = clock64();
+#endif
         w.begin(s);
         for (;;) {
             const bool go = inst && w.cont(s);
             if (!w.x.any(go)) break;
             if (go) w.iterate(s);
         }
+#ifdef MPC_PHASE_CLOCK
+        // development build: cycles per phase of the first 4096 instances, written behind the NLP
+        // residuals of a handle created with twice the capacity of the batch (tools/phase_clock.py)
+        if (SCAN && inst && k == 0 && i < 4096) {
+            double* o = m.NLPRES + 4 * (size_t)B + 8 * i;
+            for (int q = 0; q < 5; ++q) o[q] = (double)w.ph[q];
+            o[5] = (double)(clock64() - tk0); o[6] = (double)s.kk; o[7] = 0.0;
+        }
+#endif
         int hs;
         if (s.kk == c.iter_max) hs = 1;
         else if (s.alpha <= c.alpha_min) hs = 2;

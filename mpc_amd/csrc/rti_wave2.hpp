@@ -69,6 +69,12 @@ struct Wave2 : Algebra {
     static constexpr int LDS_SLOTS = PK0 + 15;
     static_assert(LDS_SLOTS <= 40, "more than 40 KB of LDS per wavefront");
     int wdiag = 0;
+#ifdef MPC_PHASE_CLOCK   // development build: s_memtime around the phases of an iteration (tools/phase_clock.py)
+    long long ph[5] = {0, 0, 0, 0, 0};
+#define MPC_PH(i, t_from, t_to) do { t_to = clock64(); ph[i] += t_to - t_from; } while (0)
+#else
+#define MPC_PH(i, t_from, t_to) do { } while (0)
+#endif
     mc_d2* mc = nullptr;
 
     struct State {
@@ -1317,9 +1323,14 @@ struct Wave2 : Algebra {
     template <bool US>
     __device__ __forceinline__ bool direction(const State& st, FwdOut& fc, double& alpha) {
         const double nci = nc_inv();
+        long long t0 = 0, t1 = 0;
+        (void)t0; (void)t1;
+        MPC_PH(0, t0, t0);   // (starts the clock: adds 0)
         factor_now<US>();
+        MPC_PH(0, t0, t1);   // factorisation scan + first right-hand side
         FwdOut fa;
         fw<false, US>(0, 0.0, fa);
+        MPC_PH(1, t1, t0);   // predictor forward pass
         const double a_aff = fa.alpha;
         const double mu_aff0 = (st.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
         const double tmp = mu_aff0 / st.mu;
@@ -1331,8 +1342,10 @@ struct Wave2 : Algebra {
 #pragma nounroll
         for (;;) {
             bw<US>(mode, sigma_mu);
+            MPC_PH(2, t0, t1);   // corrector right-hand side
             if (US) fw<true, true>(mode, sigma_mu, fc, st.musum, mu_aff0, true);
             else fw_final_seq(mode, sigma_mu, fc, st.musum, mu_aff0);
+            MPC_PH(3, t1, t0);   // corrector forward pass, acceptance test, update
             alpha = fc.alpha;
             if (!fc.redo_centering) break;
             mode = 2;
@@ -1357,7 +1370,11 @@ struct Wave2 : Algebra {
         if (fc.lin_itref) st.diag |= MPC_DIAG_ITREF;
         if (fc.lin_lq) st.diag |= MPC_DIAG_LQ;
         st.alpha = alpha;
+        long long t0 = 0, t1 = 0;
+        (void)t0; (void)t1;
+        MPC_PH(4, t0, t0);
         bu(st.musum, st.open);
+        MPC_PH(4, t0, t1);   // residuals and exit test
         st.mu = st.musum * nc_inv();
         ++st.kk;
     }
