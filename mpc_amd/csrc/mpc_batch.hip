@@ -97,7 +97,8 @@ template <class X> __device__ __forceinline__ X make_policy(int) { return X(); }
 // Batch I/O of k_wave in the C-ABI's AoS layouts (device pointers; x0, yref, yref_e and u0 are
 // required, status / qp_iter may be null): inputs are read straight from the caller's arrays
 // (the lane of stage k reads yref[i][k][0..4], coalesced) and u0 / status / qp_iter are written
-// straight back — a wave-model solve is one launch, no pack / unpack, no workspace in HBM.
+// straight back — a wave-model solve is the scan launch plus the (normally empty) list launch,
+// no pack / unpack, no workspace in HBM.
 // what a scan kernel leaves in io.status for an instance it has handed to the list kernel (which
 // overwrites it); never seen by a caller
 #define MPC_STATUS_PENDING (-1)
