@@ -68,3 +68,31 @@ def test_two_rank_sharded_solve_equals_single_process(tmp_path):
         assert tt[0] == float(world)
         times.append(tt[1])
     assert times[0] == times[1]          # the timed region's wall time is the MAX over ranks on every rank
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from mpc_amd import sharding
+    msgs = []
+    # what bench.py does on a node where RCCL cannot start: "nccl" fails on every rank (here: no
+    # GPU at all), connect() opens a fresh gloo rendezvous on the next port hosted by rank 0
+    ranks = sharding.connect("nccl", rank, world, device=None, log=msgs.append)
+    assert ranks.backend == "gloo" and ranks.world == world and msgs and "gloo" in msgs[0]
+    ranks.barrier()
+    t = ranks.max(10.0 * (rank + 1))
+    np.save(os.path.join(out_dir, f"fb_rank{rank}.npy"), np.array([t]))
+    ranks.close()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_start_failure_falls_back_to_gloo(tmp_path):
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("RCCL can start here: nothing to fall back from")
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f"fb_rank{r}.npy")[0] == 10.0 * world
