@@ -190,7 +190,9 @@ def main():
                                      "kernel_source_sha": prof.get("kernel_source_sha"), "stale": prof["stale"]}
         out["roofline"] = roof
         # ---- batch=1 latency (second half of the metric; BASELINE.md §3: >= 1000 ticks) ----
-        if not args.no_latency:
+        # (the three secondary measurements below run at N = 1 only: the other ranks of a multi-GPU
+        #  run would sit in the final barrier meanwhile)
+        if not args.no_latency and world == 1:
             sp1, wl1 = workload.make(args.variant, 1)
             s1 = capi.BatchSolver(sp1, 1, devices=[local_rank])
             lat, klat = [], []
@@ -205,7 +207,7 @@ def main():
                                     "kernel_p50": float(np.percentile(klat[10:], 50)), "ticks": 1000,
                                     "note": "mpc_batch_solve with host pointers in/out, end to end (inputs staged in pinned host memory the kernel reads directly)"}
         # ---- the same tick through the host-pointer entry point (PCIe-inclusive; never `value`) ----
-        if not args.no_e2e:
+        if not args.no_e2e and world == 1:
             e2e = {}
             hs = capi.BatchSolver(sp, B, devices=[local_rank])
             for kind in ("pageable", "pinned"):
@@ -224,7 +226,7 @@ def main():
             out["e2e_host_ms_per_step"] = dict(e2e, note="mpc_batch_solve on host numpy arrays: H2D of x0/yref/yref_e, the solve, D2H of u0/status/qp_iter; "
                                                "median of 3 warm ticks (u0 returned into pageable memory in both cases)")
         # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample, on rank 0 only ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             from tests import oracle_lib   # the only use of the oracle in this file: the thing timed as the CPU baseline
             nthr = oracle_lib.lib().oracle_max_threads()   # the box's CPU share (OMP_NUM_THREADS), not the whole machine
             ns = min(B, 32768)
