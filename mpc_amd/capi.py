@@ -148,10 +148,12 @@ class BatchSolver:
             msg = lib().mpc_batch_last_error(self._h)
             raise MpcError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
 
-    def solve(self, x0, yref, yref_e, xtraj=None, utraj=None):
+    def solve(self, x0, yref, yref_e, xtraj=None, utraj=None, u0_out=None):
         """One SQP-RTI step per instance.  Host numpy arrays in the reference's AoS layouts.
         Passing xtraj/utraj loads them as the iterate first (and returns the new iterate);
-        otherwise the handle's internal iterate is used, like an acados capsule."""
+        otherwise the handle's internal iterate is used, like an acados capsule.  Arrays that sit
+        in pinned host memory (e.g. views of torch tensors after .pin_memory()) are read in place
+        by the kernels; u0_out ([B,2] float64, C-contiguous) receives u0 instead of a new array."""
         B, N = x0.shape[0], self.N
         x0 = np.ascontiguousarray(x0, np.float64)
         yref = np.ascontiguousarray(yref, np.float64)
@@ -164,7 +166,12 @@ class BatchSolver:
             ut = np.ascontiguousarray(utraj, np.float64).copy()
             if xt.shape != (B, N + 1, 3) or ut.shape != (B, N, 2):
                 raise ValueError("expected xtraj [B,N+1,3], utraj [B,N,2]")
-        u0 = np.zeros((B, 2))
+        if u0_out is None:
+            u0 = np.zeros((B, 2))
+        else:
+            u0 = u0_out
+            if u0.shape != (B, 2) or u0.dtype != np.float64 or not u0.flags.c_contiguous:
+                raise ValueError("expected u0_out [B,2] float64, C-contiguous")
         status = np.zeros(B, np.int32)
         it = np.zeros(B, np.int32)
         rc = lib().mpc_batch_solve(self._h, B, _p(x0), _p(yref), _p(yref_e), _p(u0), _p(xt), _p(ut), _pi(status), _pi(it))
