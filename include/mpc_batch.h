@@ -91,7 +91,11 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
  *   last QP); both optional.
  * An instance whose QP fails (status 4) keeps its previous iterate and u0 is
  * the previous u_0, as the reference keeps u_current (src/optimizer.cpp:290-293).
- * Blocking.  Returns 0 or a negative code. */
+ * Blocking.  Returns 0 or a negative code.
+ * Data movement: batches of up to 64 instances go through pinned staging the kernel reads and
+ * writes itself; arrays the caller keeps in pinned memory (hipHostMalloc / hipHostRegister) are
+ * read in place by the kernels (single-device handles); pageable arrays are copied to the device,
+ * large batches in up to three chunks overlapped with the solve. */
 int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
                     const double* yref_e, double* u0, double* xtraj, double* utraj,
                     int* status, int* qp_iter);
