@@ -213,8 +213,9 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
  *      mpc_amd/csrc/consts.hpp); the instance's QP was solved again from its start by the
  *      sequential kernel (sequential Riccati recursion + the refinement of bit 1), launched behind
  *      the scan kernel on the instances it declined.  A scan direction below 1e-8 is taken as is.
- *   8  lane model only (the cross-check model): the refinement of bit 1 applied and was NOT
- *      performed */
+ *      Lane model (the cross-check model), SQP_RTI: its sweeps do not refine; an instance whose QP
+ *      reached the refinement of bit 1 was handed to the same sequential kernel
+ *   8  lane model in full SQP only: the refinement of bit 1 applied and was NOT performed */
 #define MPC_DIAG_ITREF 1
 #define MPC_DIAG_LQ 2
 #define MPC_DIAG_SCAN_FALLBACK 4

@@ -39,6 +39,10 @@ using namespace mpc;
 // kernels
 // ------------------------------------------------------------------------------------
 
+// what a scan kernel leaves in io.status for an instance it has handed to the list kernel (which
+// overwrites it); never seen by a caller
+#define MPC_STATUS_PENDING (-1)
+
 // One phase of the SQP-RTI step, one OCP per lane (H4/H15: replaces the serial loop of
 // mobile_robot_acados_batch_solve, acados_solver_mobile_robot.c:951-961).
 //
@@ -54,8 +58,9 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
                                                     int first, int min_active, int* flags) {
     const int cnt = first ? B : *count_in;
     const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
-    if (wbase >= (size_t)cnt) return;  // wave-uniform
     const unsigned l = threadIdx.x;
+    if (first && home.REDO && blockIdx.x == 0 && l == 0) home.REDO[home.redo_parity ^ 1] = 0;   // the next launch's counter (Mem::REDO)
+    if (wbase >= (size_t)cnt) return;  // wave-uniform
     const bool inrange = wbase + l < (size_t)cnt;
     // full SQP: instances whose residual check passed (or whose QP failed) sit this round out
     const bool valid = inrange && !(c.sqp && first && home.ACTIVE[wbase + l] == 0);
@@ -80,7 +85,14 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
     const bool go = valid && lane.cont(s);
     if (valid) {
         if (go) lane.save_state(s);
-        else lane.finish(s, home);
+        else if (home.REDO && (s.diag & MPC_DIAG_ITREF_SKIPPED)) {
+            // HPIPM would have refined a direction of this QP and the sweeps of this model do not
+            // (rti_core.hpp iterate): nothing is written (the rows of the iterate keep the previous
+            // one) and the instance goes to the sequential list kernel, like a declined scan step
+            const int h = (int)s.home;
+            home.REDO[MPC_REDO_LIST + atomicAdd(&home.REDO[home.redo_parity], 1)] = h;
+            home.STATUS[h] = MPC_STATUS_PENDING;
+        } else lane.finish(s, home);
     }
     if (flags && inrange) flags[wbase + l] = go ? 1 : 0;
 }
@@ -99,9 +111,6 @@ template <class X> __device__ __forceinline__ X make_policy(int) { return X(); }
 // (the lane of stage k reads yref[i][k][0..4], coalesced) and u0 / status / qp_iter are written
 // straight back — a wave-model solve is the scan launch plus the (normally empty) list launch,
 // no pack / unpack, no workspace in HBM.
-// what a scan kernel leaves in io.status for an instance it has handed to the list kernel (which
-// overwrites it); never seen by a caller
-#define MPC_STATUS_PENDING (-1)
 struct WaveIO {
     const double* x0;      // [B][3]
     const double* yref;    // [B][N][5]
@@ -1053,6 +1062,12 @@ static int pick_model(const mpc_batch* h) {
     return model;
 }
 
+// The lane model's sweeps do not refine a direction (HPIPM's itref_corr_max): an SQP_RTI instance
+// whose QP would have been refined is handed to the sequential list kernel of the wave model, which
+// solves it again with the refinement.  Full SQP (host-driven rounds in this model) keeps the lane
+// model's own result and MPC_DIAG_ITREF_SKIPPED.
+static bool lane_hands_over(const mpc_batch* h) { return h->spec.sqp_max_iter <= 1; }
+
 // The lane-model solve on inputs already packed into the workspace rows (R_X0, R_YREF, R_YREFE):
 // capsule -> rows, one RTI step (phased, with straggler compaction) or the host-driven SQP loop,
 // rows -> capsule.
@@ -1072,6 +1087,11 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
         s.mem2.slab = s.slab2;
     }
     const unsigned cgrid = (unsigned)(((size_t)n * (N + 1) + 255) / 256);
+    // `home` as the phases see it: with the list of instances handed to the sequential list kernel
+    // (lane_hands_over), or without one
+    Mem mh = m;
+    mh.redo_parity = s.redo_parity;
+    if (!lane_hands_over(h)) mh.REDO = nullptr;
     hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
     for (int it = 0; it < iters; ++it) {
         if (sqp) {
@@ -1089,7 +1109,7 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
         }
         if (n <= MPC_SINGLE_PHASE_MAX || !s.slab2) {
             HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-            hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, m, m, (const int*)nullptr, n, 1, 0, (int*)nullptr);
+            hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, m, mh, (const int*)nullptr, n, 1, 0, (int*)nullptr);
             HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
             s.n_ph = 1;
         } else {
@@ -1107,7 +1127,7 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
                 const Mem& oth = (p % 2 == 0) ? s.mem2 : m;
                 const bool last = (p == P - 1);
                 if (p == 0) HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
-                hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, cur, m, counts + p, n, p == 0 ? 1 : 0,
+                hipLaunchKernelGGL(k_phase, wgrid, wblk, 0, st, h->consts, cur, mh, counts + p, n, p == 0 ? 1 : 0,
                                    last ? 0 : MINACT, flags);
                 if (p == 0) HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
                 if (!last)
@@ -1267,6 +1287,12 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
         hipLaunchKernelGGL(k_unpack, tgrid(2, n), tb, 0, st, d_u0, 1, 2, N, (int)R_U0, m, n);
         if (d_status) HIPCHK(h, hipMemcpyAsync(d_status, m.STATUS, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
         if (d_iter) HIPCHK(h, hipMemcpyAsync(d_iter, m.QPITER, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
+        if (lane_hands_over(h)) {
+            // the list kernel reads the caller's arrays and the capsules and overwrites u0 / status /
+            // qp_iter of the instances the phases have handed over (normally none)
+            const WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
+            launch_wave(h->consts, m, n, 1, io, false, st, &s.redo_parity, false, false, MPC_LAUNCH_LIST_ONLY);
+        }
     }
     if (d_xt) unpack_iter(m, N, st, d_xt, N + 1, 3, (int)C_X, n);
     if (d_ut) unpack_iter(m, N, st, d_ut, N, 2, (int)C_U, n);
