@@ -1004,16 +1004,21 @@ static void sync_all(mpc_batch* h) {
 
 // Lane model: its workspace slab is allocated on the first solve that uses it, so a handle that
 // only ever runs the wave model holds the capsules and little else.
+// (buffer by buffer: a call that fails half-way — out of memory — leaves what it has got to the
+//  next call and to free_shard, and nothing is allocated twice)
 static int ensure_lane(mpc_batch* h, Shard& s, hipStream_t st) {
-    if (s.slab) return 0;
     const int N = h->spec.N;
     const size_t capa = (size_t)(s.cap > 0 ? s.cap : 1);
-    const size_t nbytes = slab_bytes_for(N, capa);
-    DEVALLOC(h, s, s.slab, nbytes);
-    HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, st));
-    DEVALLOC(h, s, s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int));
-    HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), st));
-    s.mem.slab = s.slab;
+    if (!s.slab) {
+        const size_t nbytes = slab_bytes_for(N, capa);
+        DEVALLOC(h, s, s.slab, nbytes);
+        HIPCHK(h, hipMemsetAsync(s.slab, 0, nbytes, st));
+        s.mem.slab = s.slab;
+    }
+    if (!s.phase_ints) {
+        DEVALLOC(h, s, s.phase_ints, (MPC_MAX_PHASES + s.S) * sizeof(int));
+        HIPCHK(h, hipMemsetAsync(s.phase_ints, 0, (MPC_MAX_PHASES + s.S) * sizeof(int), st));
+    }
     return 0;
 }
 // Device staging of the host-pointer entry points, allocated on their first use.
@@ -1021,17 +1026,17 @@ static int ensure_staging(mpc_batch* h, Shard& s, bool traj) {
     const int N = h->spec.N;
     const size_t capa = (size_t)(s.cap > 0 ? s.cap : 1);
     if (!s.staged) {
-        DEVALLOC(h, s, s.s_x0, sizeof(double) * 3 * capa);
-        DEVALLOC(h, s, s.s_yref, sizeof(double) * 5 * N * capa);
-        DEVALLOC(h, s, s.s_yrefe, sizeof(double) * 3 * capa);
-        DEVALLOC(h, s, s.s_u0, sizeof(double) * 2 * capa);
-        DEVALLOC(h, s, s.s_mask, capa);
+        if (!s.s_x0) DEVALLOC(h, s, s.s_x0, sizeof(double) * 3 * capa);
+        if (!s.s_yref) DEVALLOC(h, s, s.s_yref, sizeof(double) * 5 * N * capa);
+        if (!s.s_yrefe) DEVALLOC(h, s, s.s_yrefe, sizeof(double) * 3 * capa);
+        if (!s.s_u0) DEVALLOC(h, s, s.s_u0, sizeof(double) * 2 * capa);
+        if (!s.s_mask) DEVALLOC(h, s, s.s_mask, capa);
         s.staged = true;
     }
     if (traj && !s.staged_traj) {
-        DEVALLOC(h, s, s.s_xt, sizeof(double) * 3 * (N + 1) * capa);
-        DEVALLOC(h, s, s.s_ut, sizeof(double) * 2 * N * capa);
-        DEVALLOC(h, s, s.s_pi, sizeof(double) * 3 * N * capa);
+        if (!s.s_xt) DEVALLOC(h, s, s.s_xt, sizeof(double) * 3 * (N + 1) * capa);
+        if (!s.s_ut) DEVALLOC(h, s, s.s_ut, sizeof(double) * 2 * N * capa);
+        if (!s.s_pi) DEVALLOC(h, s, s.s_pi, sizeof(double) * 3 * N * capa);
         s.staged_traj = true;
     }
     return 0;
@@ -1729,10 +1734,14 @@ int mpc_batch_track_set_path(mpc_batch_t* h, int M, const double* state_refs, in
         HIPCHK(h, hipSetDevice(s.device));
         HIPCHK(h, hipStreamSynchronize(s.stream));
         if (s.t_sref) s.dev_bytes -= sizeof(double) * (3 * (size_t)s.t_M + 2 * (size_t)s.t_Mi);
+        if (s.t_iref && !s.t_sref) s.dev_bytes -= sizeof(double) * 2 * (size_t)s.t_Mi;   // left by a call that failed half-way
         (void)hipFree(s.t_sref); (void)hipFree(s.t_iref);
         s.t_sref = s.t_iref = nullptr;
-        DEVALLOC(h, s, s.t_sref, sizeof(double) * 3 * M);
+        s.t_M = 0;
+        // (t_iref first: mpc_batch_track_init tests t_sref, which is only set once both exist)
+        s.t_Mi = Mi;
         DEVALLOC(h, s, s.t_iref, sizeof(double) * 2 * Mi);
+        DEVALLOC(h, s, s.t_sref, sizeof(double) * 3 * M);
         HIPCHK(h, hipMemcpy(s.t_sref, state_refs, sizeof(double) * 3 * M, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(s.t_iref, input_refs, sizeof(double) * 2 * Mi, hipMemcpyHostToDevice));
         s.t_M = M; s.t_Mi = Mi;
@@ -1758,13 +1767,13 @@ int mpc_batch_track_init(mpc_batch_t* h, int B, const double* x_init, double T, 
         if (n <= 0) continue;
         if (!s.t_sref) { h->err = "mpc_batch_track_init: call mpc_batch_track_set_path first"; return -1; }
         HIPCHK(h, hipSetDevice(s.device));
-        if (!s.t_x) {
-            DEVALLOC(h, s, s.t_x, sizeof(double) * 3 * s.S);
-            DEVALLOC(h, s, s.t_u, sizeof(double) * 2 * s.S);
-            DEVALLOC(h, s, s.t_idx, sizeof(int) * 4 * s.S);
-            DEVALLOC(h, s, s.t_yref, sizeof(double) * 5 * N * s.S);
-            DEVALLOC(h, s, s.t_yrefe, sizeof(double) * 3 * s.S);
-        }
+        // (buffer by buffer, t_x last: mpc_batch_track_run tests t_x, and a call that ran out of
+        //  memory half-way is completed by the next one)
+        if (!s.t_u) DEVALLOC(h, s, s.t_u, sizeof(double) * 2 * s.S);
+        if (!s.t_idx) DEVALLOC(h, s, s.t_idx, sizeof(int) * 4 * s.S);
+        if (!s.t_yref) DEVALLOC(h, s, s.t_yref, sizeof(double) * 5 * N * s.S);
+        if (!s.t_yrefe) DEVALLOC(h, s, s.t_yrefe, sizeof(double) * 3 * s.S);
+        if (!s.t_x) DEVALLOC(h, s, s.t_x, sizeof(double) * 3 * s.S);
         HIPCHK(h, hipMemsetAsync(s.t_x, 0, sizeof(double) * 3 * s.S, s.stream));
         HIPCHK(h, hipMemcpyAsync(s.t_x, x_init + 3 * (size_t)s.first, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
         HIPCHK(h, hipMemsetAsync(s.t_u, 0, sizeof(double) * 2 * s.S, s.stream));
