@@ -104,7 +104,10 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
  * device, enqueued on `stream` (a hipStream_t, NULL = the handle's stream) and
  * NOT synchronised: for callers that keep the batch resident in HBM (bench,
  * Monte-Carlo drivers).  Single-device handles only.  No counterpart in the
- * reference beyond acados_solver_mobile_robot.c:951-961. */
+ * reference beyond acados_solver_mobile_robot.c:951-961.
+ * A handle's calls share its capsules and workspace: with a stream of the caller's, the caller
+ * orders this call against the handle's other calls (those run on the handle's own stream and
+ * wait for it before they return); two solves of one handle must never overlap. */
 int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const double* d_yref,
                            const double* d_yref_e, double* d_u0, double* d_xtraj,
                            double* d_utraj, int* d_status, int* d_qp_iter, void* stream);
