@@ -880,7 +880,8 @@ struct Shard {
     int cap = 0;       // instances this shard can hold
     size_t S = 0;      // padded stride
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the device work of the last solve ...
+    bool outer_events = false;                 // ... if that solve recorded them (the batch <= 64 path does not)
     hipEvent_t ev_ph[2] = {};   // around the dominant solve kernel of the last solve
     // host-pointer solves of large batches are pipelined in up to three chunks (65536 x N = 50 from
     // pinned arrays: 1 chunk 8.9 ms, 2: 8.0, 3: 7.9, 4: 8.1, 8: 9.1 — every chunk waits for its slowest wavefront): the inputs of chunk c + 1 travel
@@ -1435,7 +1436,7 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
     HIPCHK(h, hipSetDevice(s.device));
     HIPCHK(h, hipEventRecord(s.ev0, st));
     int rc = enqueue_solve(h, s, B, d_x0, d_yref, d_yref_e, d_u0, d_xtraj, d_utraj, d_status, d_qp_iter, st);
-    if (rc == 0) HIPCHK(h, hipEventRecord(s.ev1, st));
+    if (rc == 0) { HIPCHK(h, hipEventRecord(s.ev1, st)); s.outer_events = true; }
     return rc;
 }
 
@@ -1460,25 +1461,26 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         double* zu0 = s.z_out;
         int* zst = reinterpret_cast<int*>(zu0 + 2 * (size_t)B);
         int* zit = zst + B;
-        HIPCHK(h, hipEventRecord(s.ev0, s.stream));
-        // the scan kernel alone; the sequential list kernel follows only if something was declined
+        // the scan kernel alone; the sequential list kernel follows only if something was declined.
+        // (The only events of this path are the pair enqueue_wave records around the kernels: two
+        //  more around the call cost 10 us of the 110 us a batch = 1 tick took end to end.)
         int rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_SCAN);
         if (rc != 0) { sync_all(h); return rc; }
-        HIPCHK(h, hipEventRecord(s.ev1, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
         bool pending = false;
         for (int i = 0; i < B; ++i) pending = pending || zst[i] == MPC_STATUS_PENDING;
         if (pending) {
             rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_LIST_ONLY);
             if (rc != 0) { sync_all(h); return rc; }
-            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
             HIPCHK(h, hipStreamSynchronize(s.stream));
         }
         if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
         if (status) memcpy(status, zst, sizeof(int) * B);
         if (qp_iter) memcpy(qp_iter, zit, sizeof(int) * B);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) h->last_ms = ms;
+        if (hipEventElapsedTime(&ms, s.ev_ph[0], s.ev_ph[1]) == hipSuccess) h->last_ms = ms;
+        else (void)hipGetLastError();
+        s.outer_events = false;
         return 0;
     }
     // enqueue on every shard, then wait for all.  (Copies from pageable host memory are staged by
@@ -1505,7 +1507,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
                 rc = enqueue_solve(h, s, n, px0 + 3 * o, pyref + 5 * N * o, pyrefe + 3 * o, pu0 ? pu0 + 2 * o : s.d_u0,
                                    nullptr, nullptr, nullptr, nullptr, s.stream);
                 if (rc != 0) return rc;
-                HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+                HIPCHK(h, hipEventRecord(s.ev1, s.stream)); s.outer_events = true;
                 if (u0 && !pu0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.d_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
                 if (status) HIPCHK(h, hipMemcpyAsync(status + o, s.mem.STATUS, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
                 if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter + o, s.mem.QPITER, sizeof(int) * n, hipMemcpyDeviceToHost, s.stream));
@@ -1543,7 +1545,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
                     rc = enqueue_wave(h, s, nc, s.stream, io, model, i0, c == 0);
                     if (rc != 0) return rc;
                 }
-                HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+                HIPCHK(h, hipEventRecord(s.ev1, s.stream)); s.outer_events = true;
                 if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
             } else {
             HIPCHK(h, hipMemcpyAsync(s.s_x0, x0 + 3 * o, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s.stream));
@@ -1557,7 +1559,7 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             rc = enqueue_solve(h, s, n, s.s_x0, s.s_yref, s.s_yrefe, s.s_u0, xtraj ? s.s_xt : nullptr,
                                xtraj ? s.s_ut : nullptr, nullptr, nullptr, s.stream);
             if (rc != 0) return rc;
-            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+            HIPCHK(h, hipEventRecord(s.ev1, s.stream)); s.outer_events = true;
             if (u0) HIPCHK(h, hipMemcpyAsync(u0 + 2 * o, s.s_u0, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s.stream));
             if (xtraj) {
                 HIPCHK(h, hipMemcpyAsync(xtraj + 3 * (N + 1) * o, s.s_xt, sizeof(double) * 3 * (N + 1) * n, hipMemcpyDeviceToHost, s.stream));
@@ -1709,11 +1711,12 @@ int mpc_batch_sim_step(mpc_batch_t* h, int B, double* x, const double* u) {
 
 double mpc_batch_last_kernel_ms(mpc_batch_t* h) {
     if (!h) return -1.0;
-    if (h->shards.size() == 1) {  // device entry point: events may still be in flight
+    if (h->shards.size() == 1 && h->shards[0].outer_events) {  // device entry point: events may still be in flight
         Shard& s = h->shards[0];
         float ms = 0.f;
         if (hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess)
             h->last_ms = ms;
+        else (void)hipGetLastError();   // (events never recorded: not an error of the next launch)
     }
     return h->last_ms;
 }
@@ -1817,7 +1820,7 @@ int mpc_batch_track_run(mpc_batch_t* h, int B, int n_ticks, double* x, double* u
                                            (const unsigned char*)nullptr, n, 0);
                 }
             }
-            HIPCHK(h, hipEventRecord(s.ev1, s.stream));
+            HIPCHK(h, hipEventRecord(s.ev1, s.stream)); s.outer_events = true;
             HIPCHK(h, hipGetLastError());
         }
         return 0;
@@ -1921,8 +1924,10 @@ double mpc_batch_last_phase0_ms(mpc_batch_t* h) {
     Shard& s = h->shards[0];
     float ms = 0.f;
     if (s.n_ph < 1 || hipEventSynchronize(s.ev_ph[1]) != hipSuccess ||
-        hipEventElapsedTime(&ms, s.ev_ph[0], s.ev_ph[1]) != hipSuccess)
+        hipEventElapsedTime(&ms, s.ev_ph[0], s.ev_ph[1]) != hipSuccess) {
+        (void)hipGetLastError();
         return -1.0;
+    }
     return ms;
 }
 size_t mpc_batch_device_bytes(const mpc_batch_t* h) {
