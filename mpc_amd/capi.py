@@ -67,7 +67,7 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.mpc_spec_variant.argtypes = [ctypes.c_char_p, ctypes.POINTER(OcpSpec)]
     L.mpc_batch_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(OcpSpec), ctypes.c_int, _ip, ctypes.c_int]
-    L.mpc_batch_solve.argtypes = [_vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    L.mpc_batch_solve.argtypes = [_vp, ctypes.c_int] + [_vp] * 8     # (pointers through _fp: the batch = 1 loop)
     L.mpc_batch_solve_device.argtypes = [_vp, ctypes.c_int] + [_vp] * 8 + [_vp]
     L.mpc_batch_reset.argtypes = [_vp, ctypes.POINTER(ctypes.c_ubyte)]
     L.mpc_batch_get.argtypes = [_vp, ctypes.c_int, _dp, _dp, _dp]
@@ -105,6 +105,17 @@ def _p(a):
 
 def _pi(a):
     return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _fp(a):
+    """Pointer to a numpy array's data for a c_void_p parameter: a.ctypes.data_as() costs 2-4 us per
+    array, seven of them were a tenth of a batch = 1 tick."""
+    if a is None:
+        return None
+    try:
+        return ctypes.byref(ctypes.c_char.from_buffer(a))
+    except (TypeError, BufferError, ValueError):      # read-only or empty arrays
+        return a.ctypes.data
 
 
 def spec_variant(name):
@@ -174,7 +185,7 @@ class BatchSolver:
                 raise ValueError("expected u0_out [B,2] float64, C-contiguous")
         status = np.zeros(B, np.int32)
         it = np.zeros(B, np.int32)
-        rc = lib().mpc_batch_solve(self._h, B, _p(x0), _p(yref), _p(yref_e), _p(u0), _p(xt), _p(ut), _pi(status), _pi(it))
+        rc = lib().mpc_batch_solve(self._h, B, _fp(x0), _fp(yref), _fp(yref_e), _fp(u0), _fp(xt), _fp(ut), _fp(status), _fp(it))
         self._check(rc, "mpc_batch_solve")
         return dict(u0=u0, xtraj=xt, utraj=ut, status=status, qp_iter=it)
 
