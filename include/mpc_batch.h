@@ -230,9 +230,10 @@ int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
  *   AUTO / WAVE  the wave model, kernel chosen by horizon, mode and batch size: lane = stage(s) of
  *            one OCP, IPM workspace in registers and LDS, Riccati recursion and the two
  *            substitutions as parallel scans.  Two stages per lane (two OCPs per wavefront at
- *            N = 50, four at N <= 31, one at 64 <= N <= 127) for SQP_RTI batches of more than
- *            16384 instances; one stage per lane for smaller batches (down to the batch = 1
- *            control loop), N <= 15 and full SQP with N <= 63;
+ *            N = 50, three at 32 <= N <= 41, four at N <= 31, one at 64 <= N <= 127) for SQP_RTI
+ *            batches of more than 16384 instances (6144 where three share a wavefront); one stage
+ *            per lane for smaller batches (down to the batch = 1 control loop), N <= 15 and full
+ *            SQP with N <= 63;
  *   WAVE1    one stage per lane wherever it applies (N <= 63);   WAVE2: two stages per lane
  *            wherever it applies (N >= 16, SQP_RTI), whatever the batch size;
  *   WAVE_SEQ / WAVE2_SEQ  (one and the same) two stages per lane with the sequential recursions

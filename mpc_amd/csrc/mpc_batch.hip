@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
     constexpr int G = W::PER_BLOCK;
     const int l = threadIdx.x;
     const int g = l / GW, k = l % GW;
+    const bool grouped = g < G;   // (GW = 21: lane 63 belongs to no group and carries no instance)
     const int N = c.N;
     size_t i, ic;
     bool inst;
@@ -313,11 +314,11 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         const int cnt = m.REDO[m.redo_parity];
         const int slot0 = (int)blockIdx.x * G;
         if (slot0 >= cnt) return;
-        inst = slot0 + g < cnt;
+        inst = grouped && slot0 + g < cnt;
         i = ic = (size_t)m.REDO[MPC_REDO_LIST + (inst ? slot0 + g : slot0)];
     } else {
         i = (size_t)blockIdx.x * G + g;
-        inst = i < (size_t)B;
+        inst = grouped && i < (size_t)B;
         ic = inst ? i : (size_t)B - 1;
         if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter
     }
@@ -1155,6 +1156,10 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // part: MPC_LAUNCH_BOTH, or the scan kernel / the list kernel alone (the batch = 1 latency path
 // launches the list kernel only when the scan kernel has declined something: io.status == PENDING).
 enum { MPC_LAUNCH_BOTH = 0, MPC_LAUNCH_SCAN = 1, MPC_LAUNCH_LIST_ONLY = 2 };
+// Lanes per OCP of the two-stages-per-lane kernels: N + 1 stages need ceil((N + 1) / 2) lanes.
+// 16 / 32 / 64 lanes align with the DPP rows; 21 lanes put three OCPs of 33..42 stages (the
+// reference's N = 40 variants) into a wavefront instead of two.
+static int wave2_group_width(int N) { return N + 1 <= 32 ? 16 : N + 1 <= 42 ? 21 : N + 1 <= 64 ? 32 : 64; }
 static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
                         int* redo_parity, bool one_stage_per_lane = false, bool two_stages_per_lane = false,
                         int part = MPC_LAUNCH_BOTH) {
@@ -1168,15 +1173,17 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
 #define MPC_LAUNCH_LIST()                                                                                                 \
     do {                                                                                                                  \
         if (part == MPC_LAUNCH_SCAN) break;                                                                               \
-        const int gw = N + 1 <= 32 ? 16 : N + 1 <= 64 ? 32 : 64;                                                          \
+        const int gw = wave2_group_width(N);                                                                              \
         const int per = 64 / gw;                                                                                          \
         const dim3 grd((n + per - 1) / per), blk(64);                                                                     \
         if (sqp) {                                                                                                        \
             if (gw == 16) hipLaunchKernelGGL((k_wave2<16, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+            else if (gw == 21) hipLaunchKernelGGL((k_wave2<21, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
             else if (gw == 32) hipLaunchKernelGGL((k_wave2<32, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
             else hipLaunchKernelGGL((k_wave2<64, false, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
         } else {                                                                                                          \
             if (gw == 16) hipLaunchKernelGGL((k_wave2<16, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
+            else if (gw == 21) hipLaunchKernelGGL((k_wave2<21, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
             else if (gw == 32) hipLaunchKernelGGL((k_wave2<32, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
             else hipLaunchKernelGGL((k_wave2<64, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
         }                                                                                                                 \
@@ -1202,10 +1209,12 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
             MPC_LAUNCH_LIST();                                                                                            \
         }                                                                                                                 \
     } while (0)
+    const int gw2 = wave2_group_width(N);
     if (seq) {
         // the sequential model (cross-check; RTI only): sequential recursions + refinement, two stages per lane
-        if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
-        else if (N + 1 <= 64) MPC_LAUNCH_WAVE2(32);
+        if (gw2 == 16) MPC_LAUNCH_WAVE2(16);
+        else if (gw2 == 21) MPC_LAUNCH_WAVE2(21);
+        else if (gw2 == 32) MPC_LAUNCH_WAVE2(32);
         else MPC_LAUNCH_WAVE2(64);
     } else if (N + 1 > 64) {
         // 64 <= N <= 127: two stages per lane, one OCP per wavefront
@@ -1216,7 +1225,7 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
             MPC_LAUNCH_LIST();
         } else MPC_LAUNCH_WAVE2(64);
     } else if (one_stage_per_lane || sqp || N + 1 <= 16 ||
-               (!two_stages_per_lane && n <= 16 * MPC_SIMD_SLOTS)) {
+               (!two_stages_per_lane && n <= (gw2 == 21 ? 6 : 16) * MPC_SIMD_SLOTS)) {
         // One stage per lane: N + 1 <= 16 fills a 16-lane group as it is (four OCPs per wavefront
         // either way); full SQP keeps one OCP per wavefront where it can — OCPs that share a
         // wavefront wait for each other, and SQP iteration counts spread from 1 to 100; and batches
@@ -1224,13 +1233,16 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
         // the chip's 1024 SIMDs): a wavefront that carries half as many stages per lane finishes an
         // IPM iteration in 60 % of the time, and nothing waits for a partner OCP.  Measured kernel
         // time one stage / two stages per lane at N = 50: 1024 instances 0.26 / 0.45 ms, 4096:
-        // 0.59 / 0.72, 8192: 1.00 / 1.08, 16384: 1.80 / 1.81, 65536: 5.95 / 5.60 (N = 25 and 40 alike).
+        // 0.59 / 0.72, 8192: 1.00 / 1.08, 16384: 1.80 / 1.81, 65536: 5.95 / 5.60 (N = 25 alike).  With three
+        // OCPs per wavefront (N = 33..41) the two-stage kernel wins earlier: N = 40, 4096: 0.51 / 0.56,
+        // 8192: 0.86 / 0.77, 16384: 1.56 / 1.24.
         if (N + 1 <= 16) MPC_LAUNCH_WAVE(XWave<16>);
         else if (N + 1 <= 32) MPC_LAUNCH_WAVE(XWave<32>);
         else MPC_LAUNCH_WAVE(XWave<64>);
     } else {
-        // SQP_RTI: two stages per lane, two (N + 1 <= 64) or four (N + 1 <= 32) OCPs per wavefront
-        if (N + 1 <= 32) MPC_LAUNCH_WAVE2(16);
+        // SQP_RTI: two stages per lane, four (N + 1 <= 32), three (<= 42) or two (<= 64) OCPs per wavefront
+        if (gw2 == 16) MPC_LAUNCH_WAVE2(16);
+        else if (gw2 == 21) MPC_LAUNCH_WAVE2(21);
         else MPC_LAUNCH_WAVE2(32);
     }
 #undef MPC_LAUNCH_LIST

@@ -52,8 +52,23 @@ __device__ __forceinline__ double lane_dpp(double v) {
 }
 // All-reduce over the GW lanes of a group; every lane ends with the same bits (each step
 // combines a lane with its mirror partner, and the operations are commutative).
+__device__ __forceinline__ double lane_down(double v, int d);
+// The same for a group width that is no power of two (GW = 21: three OCPs of 33..42 stages per
+// wavefront, two stages per lane): the groups are not aligned to DPP rows, so the lanes accumulate
+// towards the group's first lane by doubling distances and that lane's value is broadcast.
+template <int GW, class Op>
+__device__ __forceinline__ double group_reduce_any_width(double v, Op op) {
+    const int l = (int)(threadIdx.x & 63), k = l % GW;
+#pragma unroll
+    for (int d = 1; d < GW; d *= 2) {
+        const double o = lane_down(v, d);
+        if (k + d < GW) v = op(v, o);
+    }
+    return __shfl(v, l - k, 64);
+}
 template <int GW, class Op>
 __device__ __forceinline__ double group_reduce(double v, Op op) {
+    if ((GW & (GW - 1)) != 0) return group_reduce_any_width<GW>(v, op);
     v = op(v, lane_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
     v = op(v, lane_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
     v = op(v, lane_dpp<0x141>(v));   // row_half_mirror
@@ -143,7 +158,7 @@ struct XWave {
     // closed-loop products of all scan distances kept in LDS (Wave::suffix_cached<true>): one matrix
     // per distance 1, 2, .., GW/2
     static constexpr bool MCACHE = true;
-    static constexpr int MC_LEVELS = GW == 64 ? 6 : GW == 32 ? 5 : 4;
+    static constexpr int MC_LEVELS = GW > 32 ? 6 : GW > 16 ? 5 : 4;
     template <int n> __device__ __forceinline__ void next(double (&v)[n]) const {
 #pragma unroll
         for (int i = 0; i < n; ++i) v[i] = lane_next(v[i]);

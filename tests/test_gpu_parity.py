@@ -405,11 +405,12 @@ def test_execution_models_agree(oracle, name, B):
 
 
 @pytest.mark.parametrize("model,N", [("wave1", n) for n in (1, 2, 7, 15, 16, 31, 32, 63)] +
-                         [("wave2", n) for n in (16, 17, 30, 31, 32, 33, 49, 50, 62, 63, 64, 65, 100, 126, 127)])
+                         [("wave2", n) for n in (16, 17, 30, 31, 32, 33, 40, 41, 42, 49, 50, 62, 63, 64, 65, 100, 126, 127)])
 def test_wave_model_group_widths(oracle, model, N):
-    """Horizons at the edges of the 16-/32-/64-lane groups of the wave kernels, one and two stages
-    per lane (several OCPs per wavefront for the narrower groups; odd and even N put the terminal
-    stage in either slot of the last lane), ragged batch."""
+    """Horizons at the edges of the 16-/21-/32-/64-lane groups of the wave kernels, one and two stages
+    per lane (several OCPs per wavefront for the narrower groups — three for 32 <= N <= 41, in groups
+    that are not aligned to the DPP rows; odd and even N put the terminal stage in either slot of
+    the last lane), ragged batch."""
     B = 37
     sp, wl = workload.make("mobile_robot", B, N=N)
     x0, yref, yref_e = wl.tick(0)
