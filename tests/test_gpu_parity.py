@@ -314,12 +314,12 @@ def test_full_sqp_matches_oracle(oracle, name, B, model):
     solver.close()
 
 
-@pytest.mark.parametrize("N", [50, 80])
+@pytest.mark.parametrize("N", [40, 50, 80])
 def test_full_sqp_carries_on_in_the_list_kernel(oracle, N):
     """Full SQP on the workload where the scan kernels decline instances (weights x 1e4, +-0.3 m
     box): a declined QP ends the instance's loop in the scan kernel with the capsule at its last
     accepted SQP iterate and the count of finished iterations in SQPITER; the sequential list kernel
-    carries on from there (k_wave<64, sqp> -> k_wave2<32, seq, sqp, list> at N = 50,
+    carries on from there (k_wave<64, sqp> -> k_wave2<32, seq, sqp, list> at N = 50, <21, ..> at N = 40,
     k_wave2<64, scan, sqp> -> k_wave2<64, seq, sqp, list> at N = 80).  Same status, same number of
     QPs and the same trajectories as the oracle's SQP loop, for the declined instances too."""
     B = 512
