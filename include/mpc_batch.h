@@ -119,7 +119,10 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
  * 36 MiB, held until the process ends) instead of in a handle:
  *   spec            as for mpc_batch_create; sqp_max_iter must be 1 (SQP_RTI)
  *   cold != 0       the first B capsules start from the all-zero iterate (a fresh handle);
- *   cold == 0       they start from the iterate the previous call ON THIS GPU left (a warm handle)
+ *   cold == 0       they start from the iterate the previous call ON THIS GPU left (a warm handle);
+ *                   refused with -1 unless the array holds iterates of the same horizon N for at
+ *                   least B capsules (the library records, per GPU, the horizon of the last cold
+ *                   call and the largest batch started at that horizon)
  *   d_x0 [B][3], d_yref [B][N][5], d_yref_e [B][3]  device pointers, in
  *   d_u0 [B][2] out (required), d_status [B], d_qp_iter [B] out (may be NULL)
  *   stream          a hipStream_t (NULL = the null stream); the call is NOT synchronised.
@@ -128,6 +131,9 @@ int mpc_batch_solve_device(mpc_batch_t* h, int B, const double* d_x0, const doub
  * argument), -2 (HIP error), -3 (no device), -4 (too large).  It calls no hipMalloc / hipFree or
  * any allocating routine; the first call on a GPU looks up that GPU's copy of the array
  * (hipGetSymbolAddress) and loads the kernels — make one call before starting a graph capture.
+ * A call recorded in a HIP graph replays correctly: everything a solve carries from launch to
+ * launch (the iterates, the list of instances handed to the sequential kernel and which of its two
+ * counters is in use) is device state, nothing is frozen into the kernel arguments at capture time.
  * Every call on a GPU shares that GPU's array and the array keeps the last call's iterates:
  * calls that overlap on one GPU (different streams or threads) race; serialise them. */
 #define MPC_STATIC_MAX_LINES 524288 /* capsule lines (64 B each) of the static workspace */

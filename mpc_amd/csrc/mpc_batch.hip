@@ -59,7 +59,10 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
     const int cnt = first ? B : *count_in;
     const size_t wbase = (size_t)blockIdx.x * MPC_WAVE;
     const unsigned l = threadIdx.x;
-    if (first && home.REDO && blockIdx.x == 0 && l == 0) home.REDO[home.redo_parity ^ 1] = 0;   // the next launch's counter (Mem::REDO)
+    // which of the two list counters this solve uses (Mem::REDO): the first phase takes the scan side's
+    // word and publishes it for the later phases and the list kernel
+    const int par = home.REDO ? (first ? home.REDO[MPC_REDO_PS] : home.REDO[MPC_REDO_PL]) : 0;
+    if (first && home.REDO && blockIdx.x == 0 && l == 0) { home.REDO[par ^ 1] = 0; home.REDO[MPC_REDO_PL] = par; }
     if (wbase >= (size_t)cnt) return;  // wave-uniform
     const bool inrange = wbase + l < (size_t)cnt;
     // full SQP: instances whose residual check passed (or whose QP failed) sit this round out
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(MPC_WAVE) void k_phase(Consts c, Mem cur, Mem home,
             // (rti_core.hpp iterate): nothing is written (the rows of the iterate keep the previous
             // one) and the instance goes to the sequential list kernel, like a declined scan step
             const int h = (int)s.home;
-            home.REDO[MPC_REDO_LIST + atomicAdd(&home.REDO[home.redo_parity], 1)] = h;
+            home.REDO[MPC_REDO_LIST + atomicAdd(&home.REDO[par], 1)] = h;
             home.STATUS[h] = MPC_STATUS_PENDING;
         } else lane.finish(s, home);
     }
@@ -134,7 +137,10 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     X xpol = make_policy<X>(l);
     Wave<X, SCAN> w(c, k, xpol);   // (no LDS: the product cache of the scans lives in registers, rti_wave.hpp Mc)
-    if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter (Mem::REDO)
+    if (SCAN && blockIdx.x == 0 && l == 0) {   // this launch's list counter (Mem::REDO)
+        const int par = m.REDO[MPC_REDO_PS];
+        m.REDO[par ^ 1] = 0; m.REDO[MPC_REDO_PL] = par;
+    }
     const bool on = inst && k <= N;
     double xi[3], ui[2], x0b[3];
 #pragma unroll
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
         if (!on) return;
         if (SCAN && s.declined) {   // nothing is written: the sequential kernel redoes this QP (k_wave2<.., LIST>)
             if (k == 0) {
-                m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+                m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
                 if (io.status) io.status[i] = MPC_STATUS_PENDING;
             }
             return;
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     if (!on || k != 0) return;
     if (redo) {
         m.SQPITER[i] = sqp_it;
-        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
         if (io.status) io.status[i] = MPC_STATUS_PENDING;
         return;
     }
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
     size_t i, ic;
     bool inst;
     if (LIST) {
-        const int cnt = m.REDO[m.redo_parity];
+        const int par = m.REDO[MPC_REDO_PL];   // this solve's list counter (Mem::REDO)
+        const int cnt = m.REDO[par];
+        if (blockIdx.x == 0 && l == 0) m.REDO[MPC_REDO_PS] = par ^ 1;   // the next scan launch counts on the other side
         const int slot0 = (int)blockIdx.x * G;
         if (slot0 >= cnt) return;
         inst = grouped && slot0 + g < cnt;
@@ -320,7 +328,10 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         i = (size_t)blockIdx.x * G + g;
         inst = grouped && i < (size_t)B;
         ic = inst ? i : (size_t)B - 1;
-        if (SCAN && blockIdx.x == 0 && l == 0) m.REDO[m.redo_parity ^ 1] = 0;   // the next launch's counter
+        if (SCAN && blockIdx.x == 0 && l == 0) {
+            const int par = m.REDO[MPC_REDO_PS];
+            m.REDO[par ^ 1] = 0; m.REDO[MPC_REDO_PL] = par;
+        }
     }
     __shared__ mc_d2 mc_lds[W::LDS_SLOTS * 64];   // product cache of the scans + parked per-stage state
     W w(c, k, mc_lds + l);
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         status = ok ? 0 : 4;
         const bool redo = SCAN && s.declined;   // nothing is written; the list kernel redoes this QP
         if (redo && inst && k == 0) {
-            m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+            m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
             if (io.status) io.status[i] = MPC_STATUS_PENDING;
         }
         if (inst && k == 0 && !redo) {
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
     }
     if (redo && inst && k == 0) {
         m.SQPITER[i] = sqp_it;
-        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.redo_parity], 1)] = (int)i;
+        m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
         if (io.status) io.status[i] = MPC_STATUS_PENDING;
     }
     if (inst && k == 0 && !redo) {
@@ -895,7 +906,6 @@ struct Shard {
     double* capbuf = nullptr;  // Mem::cap
     double* lambuf = nullptr;  // Mem::lam (full-SQP handles only)
     int* islab = nullptr;
-    int redo_parity = 0;   // see Mem::REDO
     double* d_u0 = nullptr;    // [S][2] u_0 of the last solve when the caller passes none
     // lane model only, allocated on its first use (ensure_lane)
     char* slab = nullptr;    // workspace: inputs, iterate rows, IPM workspace
@@ -982,14 +992,25 @@ static void free_shard(Shard& s) {
 // null for pageable memory: kernels then read and write the caller's arrays over the host link
 // themselves instead of going through staging buffers and copies.
 template <class T>
-static T* pinned_device_ptr(T* host) {
-    if (!host) return nullptr;
-    hipPointerAttribute_t a;
+static T* pinned_device_ptr(T* host, size_t count) {
+    if (!host || count == 0) return nullptr;
+    hipPointerAttribute_t a, b;
     if (hipPointerGetAttributes(&a, host) != hipSuccess) {
         (void)hipGetLastError();   // pageable memory is "invalid value" to the runtime
         return nullptr;
     }
     if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    // the whole span must be pinned, and in one piece: an array of which only a prefix is registered
+    // (a view that runs past a hipHostRegister'ed region, or spans two allocations) goes through
+    // the staging copies instead of faulting in a kernel
+    const char* last = reinterpret_cast<const char*>(host) + count * sizeof(T) - 1;
+    if (hipPointerGetAttributes(&b, last) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (b.type != hipMemoryTypeHost || !b.devicePointer) return nullptr;
+    if (static_cast<const char*>(b.devicePointer) - static_cast<const char*>(a.devicePointer) != last - reinterpret_cast<const char*>(host))
+        return nullptr;
     return static_cast<T*>(a.devicePointer);
 }
 
@@ -1097,7 +1118,6 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
     // `home` as the phases see it: with the list of instances handed to the sequential list kernel
     // (lane_hands_over), or without one
     Mem mh = m;
-    mh.redo_parity = s.redo_parity;
     if (!lane_hands_over(h)) mh.REDO = nullptr;
     hipLaunchKernelGGL(k_cap_slab, dim3(cgrid), dim3(256), 0, st, m, N, n, 1);   // capsule -> workspace rows
     for (int it = 0; it < iters; ++it) {
@@ -1152,7 +1172,6 @@ static int enqueue_lane(mpc_batch* h, Shard& s, int n, hipStream_t st) {
 // The wave-model launch: reads the C-ABI's arrays and the capsules and writes them back.
 // wio.x0 / yref / yref_e / u0 must be set.  seq: sequential recursions instead of the scans
 // (MPC_MODEL_WAVE_SEQ, development / cross-check; RTI only).
-// redo_parity: the caller's launch counter bit for m.REDO (toggled here by every launch that uses it).
 // part: MPC_LAUNCH_BOTH, or the scan kernel / the list kernel alone (the batch = 1 latency path
 // launches the list kernel only when the scan kernel has declined something: io.status == PENDING).
 enum { MPC_LAUNCH_BOTH = 0, MPC_LAUNCH_SCAN = 1, MPC_LAUNCH_LIST_ONLY = 2 };
@@ -1160,14 +1179,11 @@ enum { MPC_LAUNCH_BOTH = 0, MPC_LAUNCH_SCAN = 1, MPC_LAUNCH_LIST_ONLY = 2 };
 // 16 / 32 / 64 lanes align with the DPP rows; 21 lanes put three OCPs of 33..42 stages (the
 // reference's N = 40 variants) into a wavefront instead of two.
 static int wave2_group_width(int N) { return N + 1 <= 32 ? 16 : N + 1 <= 42 ? 21 : N + 1 <= 64 ? 32 : 64; }
-static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
-                        int* redo_parity, bool one_stage_per_lane = false, bool two_stages_per_lane = false,
-                        int part = MPC_LAUNCH_BOTH) {
+static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
+                        bool one_stage_per_lane = false, bool two_stages_per_lane = false, int part = MPC_LAUNCH_BOTH) {
     const int N = c.N;
     const bool sqp = sqp_max_iter > 1;
     seq = seq && !sqp;
-    Mem m = m_in;
-    m.redo_parity = *redo_parity;
     // the sequential kernel over the instances the scan kernel declined (two stages per lane, group
     // width by horizon); same grid as a full launch, blocks beyond the list return at once
 #define MPC_LAUNCH_LIST()                                                                                                 \
@@ -1187,7 +1203,6 @@ static void launch_wave(const Consts& c, const Mem& m_in, int n, int sqp_max_ite
             else if (gw == 32) hipLaunchKernelGGL((k_wave2<32, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio); \
             else hipLaunchKernelGGL((k_wave2<64, false, false, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);               \
         }                                                                                                                 \
-        *redo_parity ^= 1;                                                                                                \
     } while (0)
 #define MPC_LAUNCH_WAVE(X_)                                                                                               \
     do {                                                                                                                  \
@@ -1270,7 +1285,7 @@ static int enqueue_wave(mpc_batch* h, Shard& s, int n, hipStream_t st, const Wav
     if (first) HIPCHK(h, hipEventRecord(s.ev_ph[0], st));
     launch_wave(h->consts, i0 ? mem_slice(s.mem, i0, h->spec.N) : s.mem, n, h->spec.sqp_max_iter, wio,
                 model == MPC_MODEL_WAVE_SEQ || model == MPC_MODEL_WAVE2_SEQ, st,
-                &s.redo_parity, model == MPC_MODEL_WAVE1, model == MPC_MODEL_WAVE2, part);
+                model == MPC_MODEL_WAVE1, model == MPC_MODEL_WAVE2, part);
     HIPCHK(h, hipEventRecord(s.ev_ph[1], st));
     s.n_ph = 1;
     HIPCHK(h, hipGetLastError());
@@ -1309,7 +1324,7 @@ static int enqueue_solve(mpc_batch* h, Shard& s, int n, const double* d_x0, cons
             // the list kernel reads the caller's arrays and the capsules and overwrites u0 / status /
             // qp_iter of the instances the phases have handed over (normally none)
             const WaveIO io = {d_x0, d_yref, d_yrefe, d_u0, d_status, d_iter};
-            launch_wave(h->consts, m, n, 1, io, false, st, &s.redo_parity, false, false, MPC_LAUNCH_LIST_ONLY);
+            launch_wave(h->consts, m, n, 1, io, false, st, false, false, MPC_LAUNCH_LIST_ONLY);
         }
     }
     if (d_xt) unpack_iter(m, N, st, d_xt, N + 1, 3, (int)C_X, n);
@@ -1511,10 +1526,10 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             // per instance at its start, 23 GB/s at the headline rate) and write u0 straight back.
             const double* px0 = nullptr; const double* pyref = nullptr; const double* pyrefe = nullptr;
             if (h->shards.size() == 1 && model != MPC_MODEL_LANE && !xtraj) {
-                px0 = pinned_device_ptr(x0); pyref = pinned_device_ptr(yref); pyrefe = pinned_device_ptr(yref_e);
+                px0 = pinned_device_ptr(x0, 3 * (size_t)B); pyref = pinned_device_ptr(yref, 5 * (size_t)N * B); pyrefe = pinned_device_ptr(yref_e, 3 * (size_t)B);
             }
             if (px0 && pyref && pyrefe) {
-                double* pu0 = pinned_device_ptr(u0);
+                double* pu0 = pinned_device_ptr(u0, 2 * (size_t)B);
                 HIPCHK(h, hipEventRecord(s.ev0, s.stream));
                 rc = enqueue_solve(h, s, n, px0 + 3 * o, pyref + 5 * N * o, pyrefe + 3 * o, pu0 ? pu0 + 2 * o : s.d_u0,
                                    nullptr, nullptr, nullptr, nullptr, s.stream);
@@ -1960,7 +1975,8 @@ struct StaticScratch {
 static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
 #define MPC_STATIC_MAX_DEVICES 64
 static StaticScratch* g_scratch_ptr[MPC_STATIC_MAX_DEVICES];
-static int g_scratch_parity[MPC_STATIC_MAX_DEVICES];   // Mem::redo_parity of the next launch on that device
+static int g_scratch_N[MPC_STATIC_MAX_DEVICES];   // horizon of the iterates the array holds (0: none yet) ...
+static int g_scratch_B[MPC_STATIC_MAX_DEVICES];   // ... and how many capsules of it have been initialised
 static std::mutex g_scratch_mutex;
 // The current device's copy of `scratch` (set-up on the first call on that device), or null.
 static StaticScratch* static_scratch(int dev) {
@@ -2003,6 +2019,19 @@ int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const do
     if (hipGetDevice(&dev) != hipSuccess) return -3;
     StaticScratch* sc = static_scratch(dev);
     if (!sc) return -2;
+    {
+        // capsule lines are indexed [instance][0..N]: a warm call continues iterates of the same
+        // horizon only, and only for capsules an earlier call has initialised
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!cold && (g_scratch_N[dev] != N || B > g_scratch_B[dev])) {
+            fprintf(stderr, "mpc_batch_solve_static: warm call (cold = 0) with N = %d, B = %d, but this GPU's array holds %d "
+                            "capsules of horizon %d: start them with cold = 1\n", N, B, g_scratch_B[dev], g_scratch_N[dev]);
+            return -1;
+        }
+        if (g_scratch_N[dev] != N) g_scratch_B[dev] = 0;
+        g_scratch_N[dev] = N;
+        if (B > g_scratch_B[dev]) g_scratch_B[dev] = B;
+    }
     hipStream_t st = (hipStream_t)stream;
     Mem m;
     memset(&m, 0, sizeof(m));
@@ -2017,10 +2046,7 @@ int mpc_batch_solve_static(const mpc_ocp_spec_t* spec, int B, int cold, const do
         }
     }
     const WaveIO io = {d_x0, d_yref, d_yref_e, d_u0, d_status, d_qp_iter};
-    {
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);   // (calls that overlap on one GPU race anyway: see the header)
-        launch_wave(make_consts(*spec), m, B, 1, io, false, st, &g_scratch_parity[dev]);
-    }
+    launch_wave(make_consts(*spec), m, B, 1, io, false, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fprintf(stderr, "mpc_batch_solve_static: launch: %s\n", hipGetErrorString(e));

@@ -105,12 +105,17 @@ struct Mem {
     double* lam;         // [instance][stage 0..N][8] bound multipliers, full-SQP handles only (else null)
     double* u0;          // [S][2] u_0 of the last solve (the previous one where the QP failed)
     // Instances whose scan step was declined (rti_wave2.hpp iterate): REDO[0], REDO[1] = two counters
-    // used by alternate launches (launch t counts in REDO[t & 1] and clears the other one for launch
-    // t + 1, so no memset sits between two solves), REDO[MPC_REDO_LIST + n] = the n-th instance.
+    // used by alternate solves (a scan launch counts in one and clears the other one for the next
+    // solve, so no memset sits between two solves), REDO[MPC_REDO_LIST + n] = the n-th instance.
+    // Which counter is in use is itself device state, so that a solve recorded once in a HIP graph
+    // replays correctly: REDO[MPC_REDO_PS] is read by scan launches and written by list launches
+    // (which flip it), REDO[MPC_REDO_PL] is written by scan launches and read by the list launch
+    // behind them.  Each word is only written by the kind of launch that does not read it, and the
+    // launches of a solve are ordered on one stream.  A list launch that is skipped (latency path,
+    // nothing declined) leaves the side unchanged — its counter is then still zero.
     int* REDO;
-    int redo_parity;
 };
-enum { MPC_REDO_LIST = 64 };
+enum { MPC_REDO_LIST = 64, MPC_REDO_PS = 2, MPC_REDO_PL = 3 };
 enum : int { MPC_CAP = 8, C_X = 0, C_U = 3, C_PI = 5 };
 
 // MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK / MPC_DIAG_ITREF_SKIPPED: include/mpc_batch.h

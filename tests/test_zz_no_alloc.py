@@ -101,3 +101,76 @@ def test_static_entry_point_limits():
     r = h.solve(xb, yb, eb)
     assert np.array_equal(r["u0"], ub.cpu().numpy())
     h.close()
+
+
+def test_static_warm_call_must_match_what_the_array_holds():
+    """cold = 0 continues the iterates the previous call left: same horizon, and only capsules an
+    earlier call has initialised — anything else is refused with -1 instead of reading capsule
+    lines of another layout."""
+    torch = pytest.importorskip("torch")
+    sp, wl = workload.make("mobile_robot", 8)
+    x0, yref, yref_e = wl.tick(0)
+    d = [_dev(torch, a) for a in (x0, yref, yref_e)]
+    u0 = torch.zeros(8, 2, dtype=torch.float64, device="cuda:0")
+    sp25, wl25 = workload.make("mobile_robot_25", 8, N=25)
+    a25 = [_dev(torch, a) for a in wl25.tick(0)]
+    a = (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), u0.data_ptr())
+    b = (a25[0].data_ptr(), a25[1].data_ptr(), a25[2].data_ptr(), u0.data_ptr())
+    # (the array is shared by every test of this process: a cold call at another horizon starts the count afresh)
+    assert capi.solve_static(sp25, 4, True, *b) == 0
+    assert capi.solve_static(sp25, 4, False, *b) == 0
+    assert capi.solve_static(sp25, 8, False, *b) == -1   # capsules 4..7 never initialised at this horizon
+    assert capi.solve_static(sp, 4, False, *a) == -1     # other horizon: capsule lines of another layout
+    assert capi.solve_static(sp, 4, True, *a) == 0
+    assert capi.solve_static(sp, 4, False, *a) == 0
+    assert capi.solve_static(sp, 8, False, *a) == -1
+    assert capi.solve_static(sp25, 4, False, *b) == -1
+    torch.cuda.synchronize()
+
+
+def test_static_call_captured_in_a_graph_replays_like_a_handle():
+    """The use the entry point exists for: ONE warm call recorded in a HIP graph and replayed.  The
+    workload (cost weights x 1e4, +-0.3 m state box) makes the scan kernel decline about one instance
+    in ten, so every replay goes through the list of declined instances and the sequential kernel
+    behind it; which of the two list counters a solve uses is device state (Mem::REDO), so a replay
+    counts from zero like a fresh call.  Against a handle making the same calls: bit for bit, three
+    replays in a row."""
+    torch = pytest.importorskip("torch")
+    B = 2000
+    sp, wl = workload.make("mobile_robot", B)
+    x0, yref, yref_e = (a.copy() for a in wl.tick(0))
+    shift = x0[:, :2].copy()
+    x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+    sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sp.W), W_e=tuple(1e4 * w for w in sp.W_e))
+    d = [_dev(torch, a) for a in (x0, yref, yref_e)]
+    handle = capi.BatchSolver(sp, B, devices=[0])
+    ref, declined = [], 0
+    for r in range(4):
+        u0, st, it = _outs(torch, B)
+        torch.cuda.synchronize()
+        handle.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), u0.data_ptr(), 0, 0, st.data_ptr(), it.data_ptr())
+        handle.last_kernel_ms()
+        torch.cuda.synchronize()
+        declined += int(((handle.get_diag(B) & 4) != 0).sum())
+        ref.append((u0.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()))
+    assert declined > 4 * 0.02 * B, "the workload no longer makes the scan kernel decline anything"
+    u0, st, it = _outs(torch, B)
+    torch.cuda.synchronize()
+    # call 0: cold, eager (also looks up the array and loads the kernels before the capture starts)
+    assert capi.solve_static(sp, B, True, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), u0.data_ptr(), st.data_ptr(), it.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(u0.cpu().numpy(), ref[0][0]) and np.array_equal(it.cpu().numpy(), ref[0][2])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = capi.solve_static(sp, B, False, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), u0.data_ptr(), st.data_ptr(), it.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for r in range(1, 4):
+        st.fill_(-7); it.fill_(-7); u0.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (st.cpu().numpy() >= 0).all(), r            # no PENDING status left behind
+        assert np.array_equal(st.cpu().numpy(), ref[r][1]) and np.array_equal(it.cpu().numpy(), ref[r][2]), r
+        assert np.array_equal(u0.cpu().numpy(), ref[r][0]), r
+    handle.close()
