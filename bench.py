@@ -7,9 +7,11 @@
 
 A "step" is one control tick of the whole batch: one mpc_batch_solve_device call (one SQP-RTI
 step per instance; u0, status and iteration counts out) on inputs that are already resident in
-HBM.  Every rank owns one GPU and 65536 instances (weak scaling: the instances are independent,
-no collective on the data path; mpc_amd/sharding.py carries the barrier and the max-over-ranks
-time); value = instances solved by all ranks / max-over-ranks wall time.  Tick t tracks a window
+HBM.  Every rank owns one GPU and 65536 instances (weak scaling, the default: the instances are
+independent, no collective on the data path; mpc_amd/sharding.py carries the barrier and the
+max-over-ranks time); value = instances solved by all ranks / max-over-ranks wall time.  The same
+run also times ONE 65536 batch sharded over the ranks (strong scaling, BASELINE.json configs[2]) and
+reports it as "strong_scaling"; --scaling strong makes that the headline value instead.  Tick t tracks a window
 shifted by t waypoints from the previous iterate (the reference's warm start: no shifting of the
 trajectory, src/optimizer.cpp:208-296).
 """
@@ -78,12 +80,36 @@ def flops_model(N):
     return f0, f1, 16 * N
 
 
+# The STRUCTURED count of the same run (oracle/op_count.hpp): operations of the dense restatement
+# whose operands are not exact structural zeros / ones — what an implementation that exploits this
+# OCP's sparsity (diagonal Hessian blocks, A = I + (a, b), selections Vx / Vu, x0 eliminated) has
+# to execute.  Fitted on a WARM tick of the bench workload (on the all-zero cold iterate most of the
+# data is accidentally zero); tests/test_flops_model.py re-derives it (5 %).  Trig calls separate.
+FLOPS_MODEL_STRUCTURED = {15: (3643.0, 13540.0), 25: (6580.0, 22818.0), 40: (11583.0, 36873.0),
+                          50: (18551.0, 45813.0), 80: (333.0, 76739.0)}
+
+
+def flops_model_structured(N):
+    if N in FLOPS_MODEL_STRUCTURED:
+        return FLOPS_MODEL_STRUCTURED[N]
+    return tuple(v * N / 50.0 for v in FLOPS_MODEL_STRUCTURED[50])
+
+
+def flops_survey_8d(N, qp_iter):
+    """SURVEY.md section 8(d)'s closed form: N * 390 (RK4 on the 18-vector) + qp_iter * N * 620
+    (structured Riccati factorisation 162 + two solves 256 + barrier / step algebra ~200)."""
+    return N * 390.0 + qp_iter * N * 620.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU (weak scaling) / in all (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU solves --batch instances; strong: ONE batch of --batch instances is sharded over the GPUs "
+                         "(BASELINE.json configs[2]).  The other mode is measured too and reported as <mode>_scaling")
     ap.add_argument("--variant", default="mobile_robot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -105,63 +131,83 @@ def main():
     dev = torch.device("cuda", local_rank)
     ranks = sharding.connect(args.backend, rank, world, dev, log=lambda m: print(f"[bench] {m}", file=sys.stderr))
 
-    B, K, W = args.batch, args.steps, args.warmup
-    lo, hi = sharding.shard_range(world * B, world, rank)       # this rank's contiguous slice of the global batch
-    sp, wl = workload.make(args.variant, hi - lo, first=lo)
-    N = sp.N
-    solver = capi.BatchSolver(sp, B, devices=[local_rank])
+    K, W = args.steps, args.warmup
 
-    # inputs of every tick resident in HBM before the timed region
-    ticks = []
-    for t in range(W + K):
-        x0, yref, yref_e = wl.tick(t)
-        ticks.append((torch.from_numpy(x0).to(dev), torch.from_numpy(yref).to(dev), torch.from_numpy(yref_e).to(dev)))
-    d_u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_it = torch.zeros(B, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def step(t):
-        a, b, c = ticks[t]
-        solver.solve_device(B, a.data_ptr(), b.data_ptr(), c.data_ptr(), d_u0.data_ptr(), 0, 0, d_st.data_ptr(), d_it.data_ptr())
-
-    def sync():
-        solver.last_kernel_ms()  # synchronises the handle's stream
+    def measure(scaling):
+        """K timed ticks of this rank's slice of the global batch (sharding.rank_slice); inputs of
+        every tick resident in HBM before the timed region.  Returns the max-over-ranks wall time
+        and this rank's per-step device times."""
+        lo, hi, total = sharding.rank_slice(scaling, args.batch, world, rank)
+        n = hi - lo
+        sp_, wl_ = workload.make(args.variant, n, first=lo)
+        solver_ = capi.BatchSolver(sp_, n, devices=[local_rank])
+        ticks = []
+        for t in range(W + K):
+            x0, yref, yref_e = wl_.tick(t)
+            ticks.append((torch.from_numpy(x0).to(dev), torch.from_numpy(yref).to(dev), torch.from_numpy(yref_e).to(dev)))
+        d_u0 = torch.zeros(n, 2, dtype=torch.float64, device=dev)
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_it = torch.zeros(n, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
 
-    kernel_ms, launch_ms = [], []
+        def step(t):
+            a, b, c = ticks[t]
+            solver_.solve_device(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), d_u0.data_ptr(), 0, 0, d_st.data_ptr(), d_it.data_ptr())
 
-    def record(_t):
-        # per-step device time from HIP events on the launch stream (this waits for the step;
-        # steps are dependent through the warm start anyway)
-        kernel_ms.append(solver.last_kernel_ms())
-        launch_ms.append(solver.last_phase0_ms())
+        def sync():
+            solver_.last_kernel_ms()  # synchronises the handle's stream
+            torch.cuda.synchronize()
 
-    elapsed = sharding.timed_steps(step, sync, W, K, ranks, after_step=record)
-    qp_iter_last = d_it.cpu().numpy()
-    status_last = d_st.cpu().numpy()
+        kernel_ms, launch_ms = [], []
+
+        def record(_t):
+            # per-step device time from HIP events on the launch stream (this waits for the step;
+            # steps are dependent through the warm start anyway)
+            kernel_ms.append(solver_.last_kernel_ms())
+            launch_ms.append(solver_.last_phase0_ms())
+
+        elapsed = sharding.timed_steps(step, sync, W, K, ranks, after_step=record)
+        return dict(elapsed=elapsed, total=total, n=n, sp=sp_, wl=wl_, solver=solver_, kernel_ms=kernel_ms, launch_ms=launch_ms,
+                    qp_iter=d_it.cpu().numpy(), status=d_st.cpu().numpy())
+
+    m = measure(args.scaling)
+    # the other reading of "batch 64K @ 1-8 GPUs", measured in the same run (identical at one GPU)
+    other = "strong" if args.scaling == "weak" else "weak"
+    if world > 1:
+        mo = measure(other)
+        mo["solver"].close()
+    else:
+        mo = m
+    B, sp, wl, solver = m["n"], m["sp"], m["wl"], m["solver"]
+    N = sp.N
+    elapsed, kernel_ms, launch_ms, qp_iter_last, status_last = m["elapsed"], m["kernel_ms"], m["launch_ms"], m["qp_iter"], m["status"]
 
     if rank == 0:
-        total = world * B * K
-        value = total / elapsed
+        value = m["total"] * K / elapsed
+        per = "per GPU" if args.scaling == "weak" else "in all, sharded over the GPUs"
         out = {
-            "metric": "OCP solves/sec, mobile_robot N=50 SQP-RTI, 65536 instances per GPU",
+            "metric": f"OCP solves/sec, mobile_robot N=50 SQP-RTI, {args.batch} instances {per}",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.variant} N={N} Ts={sp.Ts} SQP-RTI (HPIPM BALANCE, qp_iter_max {sp.qp_iter_max}), "
-                                   f"{B} arc-tracking instances per GPU, warm iterate, seed {workload.SEED}",
-                       "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (independent shards, no collective)",
+                                   f"{args.batch} arc-tracking instances {per}, warm iterate, seed {workload.SEED}",
+                       "batch_per_gpu": B, "global_batch": m["total"], "horizon": N, "parallelism": f"dp{world} (independent shards, no collective)",
                        "barrier_backend": ranks.backend},
             "mean_qp_iter": float(qp_iter_last.mean()), "max_qp_iter": int(qp_iter_last.max()),
             "failed_instances": int((status_last != 0).sum()),
             "kernel_ms_per_step": float(np.mean(kernel_ms)),
             "handle_device_bytes": solver.device_bytes(),
+            # BASELINE.json configs[2] can be read either way; the other reading, same run, same protocol
+            other + "_scaling": {"scaling": other, "global_batch": mo["total"], "batch_per_gpu": mo["n"],
+                                 "value": mo["total"] * K / mo["elapsed"], "ms_per_step": 1e3 * mo["elapsed"] / K,
+                                 "kernel_ms_per_step": float(np.mean(mo["kernel_ms"]))},
         }
         # ---- roofline of the dominant kernel: the wave-model solve launch.  The binding roof is the
         #      FP64 vector unit (SURVEY.md §8d: ~60 flop per byte of batch I/O, no MFMA); the HBM
         #      figures of the same launch ride along. ----
         f0, f1, trig = flops_model(N)
+        fs0, fs1 = flops_model_structured(N)
         flops_launch = float((f0 + f1 * qp_iter_last).sum())
         bytes_launch = float(algorithmic_bytes_per_solve(N) * B)
         l_ms = float(np.mean(launch_ms))
@@ -171,9 +217,16 @@ def main():
         roof = {"bound": "fp64_vector", "kernel": "k_wave2<32,scan,rti>" if 32 < N + 1 <= 64 else "wave-model solve kernel",
                 "launch_ms": l_ms, "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
-                "flops_per_solve": flops_launch / B, "trig_calls_per_solve": trig,
-                "model": f"algorithmic flops = {f0:.0f} + {f1:.0f}*qp_iter per solve (op count of the dense SEQUENTIAL restatement; "
-                         "the parallel scans execute more, see executed_*), summed over the launch, / live HIP-event duration",
+                # the same duration priced with the two smaller counts: operations on non-structural
+                # operands only (FLOPS_MODEL_STRUCTURED), and SURVEY.md 8(d)'s closed form
+                "frac_structured": float((fs0 + fs1 * qp_iter_last).sum()) / (l_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "frac_survey_8d": float(flops_survey_8d(N, qp_iter_last).sum()) / (l_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "flops_per_solve": flops_launch / B, "flops_per_solve_structured": float((fs0 + fs1 * qp_iter_last).mean()),
+                "flops_per_solve_survey_8d": float(flops_survey_8d(N, qp_iter_last).mean()), "trig_calls_per_solve": trig,
+                "model": f"frac: algorithmic flops = {f0:.0f} + {f1:.0f}*qp_iter per solve (op count of the dense SEQUENTIAL restatement, "
+                         f"multiplies by structural zeros included); frac_structured: {fs0:.0f} + {fs1:.0f}*qp_iter (the same run, operations "
+                         "on structural 0 / 1 operands left out); frac_survey_8d: N*390 + qp_iter*N*620 (SURVEY.md 8d).  The parallel scans "
+                         "execute more than any of them (executed_*).  Summed over the launch / live HIP-event duration",
                 "traffic": None,
                 "hbm": {"algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N), "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS}}

@@ -21,6 +21,20 @@ def shard_range(total, world, rank):
     return lo, hi
 
 
+def rank_slice(scaling, batch, world, rank):
+    """This rank's contiguous slice [lo, hi) of the global batch and the global batch size.
+    "weak": every rank owns `batch` instances (the global batch grows with the world size);
+    "strong": ONE batch of `batch` instances is cut over the ranks (BASELINE.json configs[2]:
+    "batch 65536 sharded across 1/2/4/8")."""
+    if scaling == "weak":
+        lo, hi = shard_range(world * batch, world, rank)
+        return lo, hi, world * batch
+    if scaling == "strong":
+        lo, hi = shard_range(batch, world, rank)
+        return lo, hi, batch
+    raise ValueError("scaling must be 'weak' or 'strong'")
+
+
 def env_rank():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))

@@ -177,9 +177,10 @@ int oracle_rti_debug(const mpc_ocp_spec_t* spec, const double* x0, const double*
 }
 
 // Algorithmic operation count of ONE RTI step of one instance: the same
-// template run on an op-counting scalar.  out = {add/sub, mul, div, sqrt, trig, cmp/abs}.
+// template run on an op-counting scalar.  out = {add/sub, mul, div, sqrt, trig, cmp/abs,
+// structured add/sub, mul, div (op_count.hpp)}.
 int oracle_count_ops(const mpc_ocp_spec_t* spec, const double* x0, const double* yref,
-                     const double* yref_e, const double* xtraj, const double* utraj, double* out6,
+                     const double* yref_e, const double* xtraj, const double* utraj, double* out9,
                      int* qp_iter) {
     using C = opcount::Counted;
     const int N = spec->N;
@@ -196,8 +197,9 @@ int oracle_count_ops(const mpc_ocp_spec_t* spec, const double* x0, const double*
     IpmStats s;
     const int st = rti_step<C>(*spec, w, x0c, yr.data(), yre.data(), xt.data(), ut.data(), pp.data(), &it, &s);
     const opcount::Counters& c = opcount::get();
-    out6[0] = (double)c.add; out6[1] = (double)c.mul; out6[2] = (double)c.div;
-    out6[3] = (double)c.sqrt; out6[4] = (double)c.trig; out6[5] = (double)c.cmp;
+    out9[0] = (double)c.add; out9[1] = (double)c.mul; out9[2] = (double)c.div;
+    out9[3] = (double)c.sqrt; out9[4] = (double)c.trig; out9[5] = (double)c.cmp;
+    out9[6] = (double)c.s_add; out9[7] = (double)c.s_mul; out9[8] = (double)c.s_div;
     if (qp_iter) *qp_iter = it;
     return st;
 }

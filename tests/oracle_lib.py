@@ -158,13 +158,14 @@ def rti_debug(spec, x0, yref, yref_e, xtraj=None, utraj=None):
 
 
 def count_ops(spec, x0, yref, yref_e, xtraj, utraj):
-    out = np.zeros(6)
+    out = np.zeros(9)
     it = np.zeros(1, np.int32)
     st = lib().oracle_count_ops(ctypes.byref(spec), _p(np.ascontiguousarray(x0, float)),
                                 _p(np.ascontiguousarray(yref, float)), _p(np.ascontiguousarray(yref_e, float)),
                                 _p(np.ascontiguousarray(xtraj, float)), _p(np.ascontiguousarray(utraj, float)),
                                 _p(out), _pi(it))
-    return dict(status=st, qp_iter=int(it[0]), add=out[0], mul=out[1], div=out[2], sqrt=out[3], trig=out[4], cmp=out[5])
+    return dict(status=st, qp_iter=int(it[0]), add=out[0], mul=out[1], div=out[2], sqrt=out[3], trig=out[4], cmp=out[5],
+                s_add=out[6], s_mul=out[7], s_div=out[8])
 
 
 # ---- the reference's own CasADi functions (oracle/_ref), for golden-vector generation ----

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, total, out_dir):
+def _worker(rank, world, port, scaling, batch, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, total, out_dir):
     # a contiguous shard per rank, timed_steps (warm-up, barrier-bracketed timed region, MAX over ranks)
     ranks = sharding.connect("gloo", rank, world)
     assert ranks.world == world and ranks.backend == "gloo"
-    lo, hi = sharding.shard_range(total, world, rank)
+    lo, hi, total = sharding.rank_slice(scaling, batch, world, rank)   # bench.py's own call, both of its modes
     sp, wl = workload.make("mobile_robot_18", hi - lo, first=lo)
     state = {"x": None, "u": None, "r": None, "seen": []}
 
@@ -47,13 +47,17 @@ def _worker(rank, world, port, total, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_solve_equals_single_process(tmp_path):
+@pytest.mark.parametrize("scaling,batch,total", [("strong", 37, 37), ("weak", 18, 36)])
+def test_two_rank_sharded_solve_equals_single_process(tmp_path, scaling, batch, total):
+    """strong: ONE batch of 37 cut into ragged shards of 18 and 19 (BASELINE.json configs[2]);
+    weak: 18 instances per rank, global batch 36 (bench.py's default)."""
     import torch.multiprocessing as mp
-    from mpc_amd import workload
+    from mpc_amd import sharding, workload
     from tests import hostcore_lib
-    total, world = 37, 2   # ragged on purpose: shards of 18 and 19
+    world = 2
+    assert [sharding.rank_slice(scaling, batch, world, r)[2] for r in range(world)] == [total, total]
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, scaling, batch, str(tmp_path)), nprocs=world, join=True)
     sp, wl = workload.make("mobile_robot_18", total)
     xo = uo = None
     for t in range(3):   # warm-up tick + two timed ticks, as in the workers
