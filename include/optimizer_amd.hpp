@@ -19,6 +19,7 @@
 // tests/cpp/optimizer_surface_main.cpp calls each of them (stand-in types: this image has neither
 // Eigen nor ROS, so a build of controller.cpp itself against this header has NOT been made).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -120,7 +121,7 @@ class Optimizer {
         }
         if (this->v_ref > 0.3) this->v_ref = 0.35;   // src/optimizer.cpp:174
     }
-    ~Optimizer() { mpc_batch_free(mpc_); mpc_batch_free(mpc_park_); }
+    ~Optimizer() { mpc_batch_free(mpc_); mpc_batch_free(mpc_park_); mpc_batch_free(mpc_plant50_); }
     Optimizer(const Optimizer&) = delete;
     Optimizer& operator=(const Optimizer&) = delete;
 
@@ -144,6 +145,7 @@ class Optimizer {
     }
 
     int update_and_solve(Vector3d& i_current_state, bool safety_check = true, int mode = -1) {   // :208-319
+        const auto t_start = std::chrono::high_resolution_clock::now();   // debug timer (:214)
         // mode selects the waypoint table (:215-226); a table that was never filled (the reference
         // leaves all three empty, :147-149, and would index out of range) falls back to state_refs
         if (mode == -1) state_refs_ptr = &state_refs;
@@ -179,12 +181,31 @@ class Optimizer {
             return 1;
         }
         u_current[0] = u0[0]; u_current[1] = u0[1];
-        if (debug) record_tick(i_current_state);   // :300-317
+        if (debug) {   // :300-317
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();
+            record_tick(i_current_state, ms);
+        }
         return 0;
     }
 
-    void integrate_next_states() {   // :321-341
-        mpc_batch_sim_step(mpc_, 1, x_current.data(), u_current);
+    // One ERK4 step of the plant (:321-341).  The step length is the solver variant's own Ts.
+    // For the 18 cm/s variant the reference's code does not say that: its else-branch (:328-332) calls
+    // mobile_robot_acados_sim_solve(sim_capsule) — the N = 50 variant's integrator, Ts = 0.05 — on a
+    // capsule that the use18 constructor branch never created (:87-110), i.e. undefined behaviour that
+    // cannot be reproduced.  `use18_plant_as_written` = true takes the branch by its letter, as if that
+    // capsule had been created: the plant then advances 0.05 s per tick while the OCP assumes 0.125 s.
+    void integrate_next_states() {
+        if (use18 && use18_plant_as_written) {
+            if (!mpc_plant50_) {
+                mpc_ocp_spec_t sp;
+                if (mpc_spec_variant("mobile_robot", &sp) || mpc_batch_create(&mpc_plant50_, &sp, 1, nullptr, 0))
+                    throw std::runtime_error("acados integrator returned status 1. Exiting.");
+            }
+            if (mpc_batch_sim_step(mpc_plant50_, 1, x_current.data(), u_current))
+                throw std::runtime_error("acados integrator returned status 1. Exiting.");
+        } else if (mpc_batch_sim_step(mpc_, 1, x_current.data(), u_current)) {
+            throw std::runtime_error("acados integrator returned status 1. Exiting.");   // :333-335
+        }
         t0 += T;
     }
 
@@ -325,6 +346,7 @@ class Optimizer {
         frame2[0] = frame2[1] = frame2[2] = 0.0;
     }
     int update_and_solve_park(const double xs[5], double thresh_sq = 0.0025) {
+        const auto t_start = std::chrono::high_resolution_clock::now();   // include/optimizer.hpp:192
         transform_point(x_current, x_current_transformed, frame1, frame2);
         while (x_current_transformed[2] - frame2[2] > M_PI) x_current_transformed[2] -= 2 * M_PI;
         while (x_current_transformed[2] - frame2[2] < -M_PI) x_current_transformed[2] += 2 * M_PI;
@@ -339,33 +361,50 @@ class Optimizer {
         status = st;
         if (status != 0) return 1;
         u_current[0] = u0[0]; u_current[1] = u0[1];
-        if (debug) record_tick(x_current);   // :223-236
+        if (debug) record_tick(x_current, std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count());   // :223-236
         return 0;
     }
 
     // ---- statistics of the recorded run (src/optimizer.cpp:472-518) ----
     // [mean speed, mean steer, mean |d speed|, mean |d steer|, mean |x err|, mean |y err|, mean |yaw err|]
-    // over the `iter` recorded ticks (the reference averages the errors over its whole zero-padded
-    // 2*num_waypoints buffers; the padding is left out here).  Files are written only when
-    // `results_dir` is set (the reference writes next to its sources).
+    // and the tick timing the reference prints (:476-478): time_stats = {mean, max, min} in ms.
+    // reference_stats = true (default) gives the reference's numbers: its error buffers are
+    // 2*num_waypoints long and zero beyond the recorded ticks, and .mean() runs over all of them
+    // (:166-171, 496-499), so the three error means are sum / (2*num_waypoints); its time_record is a
+    // (2*num_waypoints) x nu matrix written through the linear index (:172, 304) and resized to
+    // iter x nu (:475), so "average" is sum / (nu*iter) and "min" is 0 (the second column is never
+    // written).  reference_stats = false averages over the recorded ticks only.  A run longer than
+    // 2*num_waypoints ticks overruns the reference's buffers; here the record grows.
+    // Files are written only when `results_dir` is set (the reference writes next to its sources).
     VectorXd computeStats(int hsy = 0) {
         (void)hsy;
         const int n = iter;
         VectorXd stats(7);
         for (int q = 0; q < 7; ++q) stats(q) = 0.0;
+        time_stats[0] = time_stats[1] = time_stats[2] = 0.0;
         if (n == 0) return stats;
+        double tsum = 0.0, tmax = time_ms_[0], tmin = time_ms_[0];
         for (int k = 0; k < n; ++k) {
             stats(0) += simU_[2 * k]; stats(1) += simU_[2 * k + 1];
             if (k) { stats(2) += std::abs(simU_[2 * k] - simU_[2 * k - 2]); stats(3) += std::abs(simU_[2 * k + 1] - simU_[2 * k - 1]); }
             stats(4) += std::abs(err_[3 * k]); stats(5) += std::abs(err_[3 * k + 1]);
             stats(6) += std::abs(std::atan2(std::sin(err_[3 * k + 2]), std::cos(err_[3 * k + 2])));
+            tsum += time_ms_[k]; tmax = std::max(tmax, time_ms_[k]); tmin = std::min(tmin, time_ms_[k]);
         }
-        stats(0) /= n; stats(1) /= n; stats(4) /= n; stats(5) /= n; stats(6) /= n;
+        const double nerr = (reference_stats && num_waypoints > 0) ? 2.0 * num_waypoints : (double)n;   // (no buffers at all without waypoints)
+        stats(0) /= n; stats(1) /= n; stats(4) /= nerr; stats(5) /= nerr; stats(6) /= nerr;
         if (n > 1) { stats(2) /= n - 1; stats(3) /= n - 1; }
-        simX = MatrixXd(n, 3); simU = MatrixXd(n, 2);
+        time_stats[0] = reference_stats ? tsum / (2.0 * n) : tsum / n;
+        time_stats[1] = tmax;
+        time_stats[2] = reference_stats ? 0.0 : tmin;
+        printf("average estimation time %f ms \n", time_stats[0]);
+        printf("max estimation time %f ms \n", time_stats[1]);
+        printf("min estimation time %f ms \n", time_stats[2]);
+        simX = MatrixXd(n, 3); simU = MatrixXd(n, 2); time_record = MatrixXd(n, 2);
         for (int k = 0; k < n; ++k) {
             for (int q = 0; q < 3; ++q) simX(k, q) = simX_[3 * k + q];
             for (int q = 0; q < 2; ++q) simU(k, q) = simU_[2 * k + q];
+            time_record(k, 0) = time_ms_[k]; time_record(k, 1) = 0.0;
         }
         if (!results_dir.empty()) {
             saveToFile(simX, results_dir + "/simX.txt");
@@ -416,10 +455,13 @@ class Optimizer {
     Vector3d x_current, x_real, frame1, frame2, x_current_transformed;
     double u_current[2] = {0.0, 0.0};
     bool shift_warm_start = false;   // extension (mpc_batch_shift); false = the reference's behaviour
+    bool reference_stats = true;     // computeStats: the reference's zero-padded means (see there)
+    bool use18_plant_as_written = false;   // integrate_next_states: see there
+    double time_stats[3] = {0.0, 0.0, 0.0};   // {mean, max, min} tick time in ms, set by computeStats (:476-478)
     MatrixXd state_refs, input_refs, normals, left_turn_states, right_turn_states, straight_states;
     MatrixXd* state_refs_ptr = &state_refs;
     VectorXd state_attributes;
-    MatrixXd simX, simU;        // filled by computeStats() from the recorded ticks
+    MatrixXd simX, simU, time_record;   // filled by computeStats() from the recorded ticks (time_record: ms, column 0)
     std::string results_dir;    // where computeStats() writes its files; empty = nowhere
     static constexpr double rdb_circumference = 3.95;
 
@@ -427,15 +469,17 @@ class Optimizer {
     void set_path_loaded() { num_waypoints = (int)state_refs.rows(); state_refs_ptr = &state_refs; }
     // per-tick record behind computeStats (the reference's simX / simU / *_errors, which it sizes
     // 2*num_waypoints and overruns on longer runs; these grow)
-    void record_tick(const Vector3d& state) {
+    void record_tick(const Vector3d& state, double elapsed_ms) {
+        time_ms_.push_back(elapsed_ms);
         const int t = std::min(target_waypoint_index, (int)state_refs.rows() - 1);
         simU_.push_back(u_current[0]); simU_.push_back(u_current[1]);
         for (int q = 0; q < 3; ++q) simX_.push_back(state[q]);
         for (int q = 0; q < 3; ++q) err_.push_back(t >= 0 ? state_refs(t, q) - x_real[q] : 0.0);
         iter++;
     }
-    std::vector<double> simX_, simU_, err_;
+    std::vector<double> simX_, simU_, err_, time_ms_;
     mpc_batch_t* mpc_ = nullptr;
+    mpc_batch_t* mpc_plant50_ = nullptr;   // use18_plant_as_written only
     mpc_batch_t* mpc_park_ = nullptr;
     int limit_ = -1, lookahead_ = 1, count_ = 0;   // function-statics of the reference, per object
     double park_xs_[5] = {0, 0, 0, 0, 0};

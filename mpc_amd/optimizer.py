@@ -18,6 +18,7 @@ The reference keeps `limit`, `lookahead`, `last_state`, `count` in function-stat
 (:387-403), which makes it non-reentrant; here they are per-instance members.
 """
 import math
+import time
 
 import numpy as np
 
@@ -79,6 +80,7 @@ class Optimizer:
         self.status = 0
         self.debug = True
         factory = solver_factory or _gpu_solver
+        self._factory = factory
         self.variant = variant_for_speed(self.v_ref_int)
         self.use25 = self.variant == "mobile_robot_25"
         self.use18 = self.variant == "mobile_robot_18"
@@ -112,8 +114,14 @@ class Optimizer:
         self.iter = 0
         # per-tick record behind computeStats (the reference's simX / simU / *_errors buffers, which
         # it sizes 2*num_waypoints and overruns on longer runs; these grow)
-        self._simX, self._simU, self._err = [], [], []
+        self._simX, self._simU, self._err, self._time_ms = [], [], [], []
         self.results_dir = None
+        # computeStats: True = the reference's zero-padded means and its time_record arithmetic
+        self.reference_stats = True
+        self.time_stats = np.zeros(3)          # [mean, max, min] tick time in ms, set by computeStats
+        # integrate_next_states for the 18 cm/s variant: see there
+        self.use18_plant_as_written = False
+        self._solver_plant50 = None
         if self.v_ref > 0.3:
             self.v_ref = 0.35  # src/optimizer.cpp:174
         # per-instance versions of the function-statics of find_next_waypoint / find_closest_waypoint
@@ -194,6 +202,7 @@ class Optimizer:
     # ------------------------------------------------------------------ the tick (H1)
     def update_and_solve(self, i_current_state=None, safety_check=True, mode=-1):
         """Returns 0 if successful, 1 otherwise; the control is left in `u_current`."""
+        t_start = time.perf_counter()   # debug timer (src/optimizer.cpp:214)
         if i_current_state is None:
             i_current_state = self.x_current
         if mode == -1:
@@ -218,11 +227,12 @@ class Optimizer:
             return 1
         self.u_current = out["u0"][0].copy()
         if self.debug:
-            self._record_tick(i_current_state)
+            self._record_tick(i_current_state, 1e3 * (time.perf_counter() - t_start))
         return 0
 
-    def _record_tick(self, state):
+    def _record_tick(self, state, elapsed_ms=0.0):
         """src/optimizer.cpp:300-317 / include/optimizer.hpp:223-236."""
+        self._time_ms.append(float(elapsed_ms))
         t = min(self.target_waypoint_index, self.state_refs.shape[0] - 1)
         self._simU.append(np.array(self.u_current, np.float64))
         self._simX.append(np.array(state, np.float64))
@@ -237,13 +247,25 @@ class Optimizer:
     def simU(self):
         return np.array(self._simU).reshape(-1, 2)
 
+    @property
+    def time_record(self):
+        """[iter, nu] like the reference's (src/optimizer.cpp:172,304,475): ms in column 0, column 1 never written."""
+        t = np.zeros((len(self._time_ms), 2))
+        t[:, 0] = self._time_ms
+        return t
+
     def computeStats(self, hsy=0):
         """src/optimizer.cpp:472-518: [mean speed, mean steer, mean |d speed|, mean |d steer|,
-        mean |x err|, mean |y err|, mean |yaw err|] over the recorded ticks (the reference averages
-        the errors over its zero-padded buffers; the padding is left out).  Files only when
-        `results_dir` is set."""
+        mean |x err|, mean |y err|, mean |yaw err|]; the tick timing of :476-478 goes to `time_stats`
+        (mean, max, min in ms) and is printed.  reference_stats (default): the reference's numbers —
+        its error buffers are 2*num_waypoints long, zero beyond the recorded ticks, and .mean() runs
+        over all of them (:166-171, 496-499); its time_record is resized to [iter, nu] with only the
+        first column ever written (:172, 304, 475), so its "average" is sum / (nu*iter) and its "min" 0.
+        reference_stats = False: means over the recorded ticks only.  Files only when `results_dir`
+        is set."""
         n = self.iter
         stats = np.zeros(7)
+        self.time_stats = np.zeros(3)
         if n == 0:
             return stats
         U, E = self.simU, np.array(self._err).reshape(-1, 3)
@@ -251,8 +273,17 @@ class Optimizer:
         if n > 1:
             dU = np.abs(np.diff(U, axis=0))
             stats[2], stats[3] = dU[:, 0].mean(), dU[:, 1].mean()
-        stats[4], stats[5] = np.abs(E[:, 0]).mean(), np.abs(E[:, 1]).mean()
-        stats[6] = np.abs(np.arctan2(np.sin(E[:, 2]), np.cos(E[:, 2]))).mean()
+        nerr = 2.0 * self.num_waypoints if (self.reference_stats and self.num_waypoints > 0) else float(n)
+        stats[4], stats[5] = np.abs(E[:, 0]).sum() / nerr, np.abs(E[:, 1]).sum() / nerr
+        stats[6] = np.abs(np.arctan2(np.sin(E[:, 2]), np.cos(E[:, 2]))).sum() / nerr
+        tm = np.asarray(self._time_ms)
+        if self.reference_stats:
+            self.time_stats = np.array([tm.sum() / (2.0 * n), tm.max(), 0.0])
+        else:
+            self.time_stats = np.array([tm.mean(), tm.max(), tm.min()])
+        print("average estimation time %f ms " % self.time_stats[0])
+        print("max estimation time %f ms " % self.time_stats[1])
+        print("min estimation time %f ms " % self.time_stats[2])
         if self.results_dir:
             np.savetxt(f"{self.results_dir}/simX.txt", self.simX)
             np.savetxt(f"{self.results_dir}/simU.txt", U)
@@ -316,8 +347,17 @@ class Optimizer:
         return 0 if best == 4 else best
 
     def integrate_next_states(self):
-        """src/optimizer.cpp:321-341 (H16): one ERK4 step of the variant's Tsim."""
-        self.x_current = self._solver.sim_step(self.x_current.reshape(1, 3), self.u_current.reshape(1, 2))[0]
+        """src/optimizer.cpp:321-341 (H16): one ERK4 step of the variant's Tsim.  For the 18 cm/s
+        variant the reference's else-branch (:328-332) names the N = 50 variant's integrator
+        (Ts = 0.05) on a capsule its use18 constructor branch never created — undefined behaviour
+        that cannot be reproduced; `use18_plant_as_written` takes the branch by its letter, as if
+        that capsule had been created (the plant then advances 0.05 s per tick)."""
+        solver = self._solver
+        if self.use18 and self.use18_plant_as_written:
+            if self._solver_plant50 is None:
+                self._solver_plant50 = self._factory(variants.spec("mobile_robot"))
+            solver = self._solver_plant50
+        self.x_current = solver.sim_step(self.x_current.reshape(1, 3), self.u_current.reshape(1, 2))[0]
         self.t0 += self.T
 
     def update_current_states(self, x, y, yaw, state=None, safety_check=True):
@@ -399,6 +439,7 @@ class Optimizer:
 
     def update_and_solve_park(self, xs, thresh_sq=0.0025):
         """include/optimizer.hpp:191-238.  0 ok, 1 solver error, 2 target reached."""
+        t_start = time.perf_counter()   # include/optimizer.hpp:192
         xs = np.asarray(xs, np.float64)
         xt = self.transform_point(self.x_current, self.frame1, self.frame2)
         yaw_frame2 = self.frame2[2]
@@ -419,10 +460,10 @@ class Optimizer:
             return 1
         self.u_current = out["u0"][0].copy()
         if self.debug:
-            self._record_tick(self.x_current)
+            self._record_tick(self.x_current, 1e3 * (time.perf_counter() - t_start))
         return 0
 
     def close(self):
-        for s in (self._solver, self._solver_park):
+        for s in (self._solver, self._solver_park, self._solver_plant50):
             if hasattr(s, "close"):
                 s.close()

@@ -115,9 +115,21 @@ int main(int argc, char** argv) {
     printf("park %d %d\n", status, i);
     p3("xt", mpc.x_current_transformed);
 
+    // computeStats as the reference computes it (zero-padded 2*num_waypoints buffers, src/optimizer.cpp:496-499;
+    // the tick timing of :476-478), then over the recorded ticks only
+    mpc.num_waypoints = (int)mpc.state_refs.rows();   // what the constructor sets when it loads the path files (:160)
     const VectorXd stats = mpc.computeStats(357);                                              // :1645
     printf("stats %d", mpc.iter);
     for (int q = 0; q < 7; ++q) printf(" %.17g", stats(q));
     printf("\nsim %d %d %.17g %.17g\n", (int)mpc.simX.rows(), (int)mpc.simU.rows(), mpc.simX(3, 1), mpc.simU(3, 0));
+    printf("time %d %d %.17g %.17g %.17g\n", (int)mpc.time_record.rows(), (int)mpc.time_record.cols(), mpc.time_stats[0], mpc.time_stats[1], mpc.time_stats[2]);
+    double tsum = 0.0;
+    for (int k = 0; k < (int)mpc.time_record.rows(); ++k) tsum += mpc.time_record(k, 0);
+    mpc.reference_stats = false;
+    const VectorXd stats2 = mpc.computeStats(357);
+    printf("stats_ticks %d", mpc.iter);
+    for (int q = 0; q < 7; ++q) printf(" %.17g", stats2(q));
+    printf("\ntime %d %d %.17g %.17g %.17g\n", (int)mpc.time_record.rows(), (int)mpc.time_record.cols(), mpc.time_stats[0], mpc.time_stats[1], mpc.time_stats[2]);
+    printf("timesum %.17g\n", tsum);
     return 0;
 }

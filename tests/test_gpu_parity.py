@@ -484,7 +484,9 @@ def test_cpp_optimizer_surface():
     out = subprocess.run([exe, sf, uf], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Invalid mode" in out.stderr
-    rows = [l.split() for l in out.stdout.strip().splitlines()]
+    lines = out.stdout.strip().splitlines()
+    assert sum("estimation time" in l for l in lines) == 6     # computeStats prints mean / max / min tick time, twice here
+    rows = [l.split() for l in lines if "estimation time" not in l]
     pos = [0]
 
     def take(tag):
@@ -560,9 +562,24 @@ def test_cpp_optimizer_surface():
     close(take("park"), [st, k])
     assert st in (0, 2)   # no solver error; reaching the pose from this heading is not the point here
     close(take("xt"), o.x_current_transformed)
+    # computeStats in the reference's arithmetic (errors averaged over the zero-padded 2*num_waypoints
+    # buffers, src/optimizer.cpp:496-499), then over the recorded ticks only
+    assert o.reference_stats and o.num_waypoints == M
     stats = o.computeStats(357)
     close(take("stats"), [o.iter, *stats], 1e-11)
     close(take("sim"), [o.simX.shape[0], o.simU.shape[0], o.simX[3, 1], o.simU[3, 0]])
+    t_ref = take("time")
+    o.reference_stats = False
+    stats_ticks = o.computeStats(357)
+    close(take("stats_ticks"), [o.iter, *stats_ticks], 1e-11)
+    t_tick = take("time")
+    tsum = take("timesum")[0]
+    assert np.allclose(stats[4:7] * (2 * M), stats_ticks[4:7] * o.iter, rtol=1e-12) and np.array_equal(stats[:4], stats_ticks[:4])
+    # tick timing (:301-304, 476-478): iter x nu record; reference mode: mean = sum / (nu * iter), min = 0
+    assert t_ref[:2] == [o.iter, 2] and t_tick[:2] == [o.iter, 2]
+    assert abs(t_ref[2] - tsum / (2 * o.iter)) < 1e-9 and t_ref[4] == 0.0 and t_ref[3] >= t_ref[2] > 0
+    assert abs(t_tick[2] - tsum / o.iter) < 1e-9 and 0 < t_tick[4] <= t_tick[2] <= t_tick[3] == t_ref[3]
+    assert o.time_record.shape == (o.iter, 2) and (o.time_record[:, 0] > 0).all() and (o.time_record[:, 1] == 0).all()
     assert pos[0] == len(rows)
     o.close()
 
@@ -591,6 +608,78 @@ def test_config1_closed_loop_n18_variant():
     d = np.hypot(s[:, 0] - og.x_current[0], s[:, 1] - og.x_current[1]).min()
     assert d < 0.08 and og.x_current[0] > 1.0       # it follows the path and makes progress
     og.close()
+
+
+def test_config1_optimizer_main_on_path118():
+    """BASELINE configs[0] as the reference words it: the 18 cm/s variant (mobile_robot_18: N = 40,
+    Ts = 0.125) run by the C++ `optimizer_main` loop (src/optimizer_main.cpp:3-16, src/optimizer.cpp:
+    138-160,177-206) — constructor loading the reference's own path files scripts/paths/*_path118.txt
+    (their first 700 rows: tests/golden/path118, made by make_path118_fixture.py), start on the first
+    waypoint, update_and_solve + integrate_next_states per tick, computeStats — through
+    include/optimizer_amd.hpp (tests/cpp/optimizer_main_amd.cpp), 250 ticks.  Against the Python
+    mirror driving (a) the same GPU library: every tick to 1e-12, and (b) the CPU oracle: target index
+    exact, commands and states within 1e-6.  Then the plant-step switch for the reference's `use18`
+    branch (src/optimizer.cpp:328-332), C++ against the Python mirror."""
+    import os
+    import subprocess
+    from mpc_amd.optimizer import Optimizer
+    from tests.oracle_solver import OracleSolver
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "_build", "optimizer_main_amd")
+    assert os.path.exists(exe), "build it with `make -C tests/cpp` (done by __graft_entry__.build())"
+    pdir = os.path.join(here, "golden", "path118")
+    T, v_ref, n = 0.125, 0.18, 250
+
+    def run_cpp(flag):
+        out = subprocess.run([exe, pdir, str(T), str(v_ref), str(n), str(flag)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [l.split() for l in out.stdout.strip().splitlines() if "estimation time" not in l]
+        return rows
+
+    rows = run_cpp(0)
+    og = Optimizer(T, 40, v_ref, paths_dir=pdir)
+    oo = Optimizer(T, 40, v_ref, paths_dir=pdir, solver_factory=OracleSolver)
+    assert rows[0][0] == "ctor" and [int(v) for v in rows[0][1:6]] == [40, 700, 700, 700, 700]
+    assert og.variant == "mobile_robot_18" and og.N == 40 and og.num_waypoints == 700 and abs(float(rows[0][6]) - og.density) < 1e-12
+    for o in (og, oo):
+        o.x_current = o.state_refs[0, :3].copy()
+    ticks = [r for r in rows if r[0] == "tick"]
+    assert len(ticks) == n
+    worst = 0.0
+    for k in range(n):
+        rg, ro = og.update_and_solve(og.x_current), oo.update_and_solve(oo.x_current)
+        og.integrate_next_states(); oo.integrate_next_states()
+        row = ticks[k]
+        assert int(row[1]) == rg == ro == 0
+        assert int(row[2]) == og.target_waypoint_index == oo.target_waypoint_index, k
+        got = np.array([float(v) for v in row[3:8]])
+        assert np.abs(got - np.concatenate([og.u_current, og.x_current])).max() < 1e-12, k
+        dev = np.abs(got - np.concatenate([oo.u_current, oo.x_current])).max()
+        worst = max(worst, dev)
+        assert dev < TOL_HARD, (k, dev)
+    assert og.target_waypoint_index > 200          # about one waypoint per tick (0.18 m/s * 0.125 s = 1 / density)
+    d = np.hypot(og.state_refs[:, 0] - og.x_current[0], og.state_refs[:, 1] - og.x_current[1]).min()
+    assert d < 0.05
+    st = [r for r in rows if r[0] == "stats"][0]
+    stats = og.computeStats(0)
+    assert int(st[1]) == og.iter == n and np.abs(np.array([float(v) for v in st[2:9]]) - stats).max() < 1e-11
+    print(f"config 1 on path118: 250 ticks, GPU (C++ front-end) vs oracle (Python mirror) max deviation {worst:.2e}")
+    og.close()
+    # the `use18` plant step by the letter of the reference's else-branch: the N = 50 variant's integrator (Ts = 0.05)
+    rows = run_cpp(1)
+    ow = Optimizer(T, 40, v_ref, paths_dir=pdir)
+    ow.use18_plant_as_written = True
+    ow.x_current = ow.state_refs[0, :3].copy()
+    ticks = [r for r in rows if r[0] == "tick"]
+    for k in range(60):
+        ow.update_and_solve(ow.x_current)
+        x_before = ow.x_current.copy()
+        ow.integrate_next_states()
+        got = np.array([float(v) for v in ticks[k][3:8]])
+        assert np.abs(got - np.concatenate([ow.u_current, ow.x_current])).max() < 1e-12, k
+        step = np.hypot(*(ow.x_current[:2] - x_before[:2]))
+        assert abs(step - abs(ow.u_current[0]) * 0.05) < 1e-6      # 0.05 s of travel per tick, not 0.125 s
+    ow.close()
 
 
 def test_config2_batch_4096_n25_variant(oracle):
