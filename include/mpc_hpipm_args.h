@@ -34,6 +34,19 @@
 #define MPC_IPM_T_MIN 1e-16
 #define MPC_IPM_TAU_MIN 1e-16
 #define MPC_IPM_SPLIT_STEP 0         /* one step length for primal and dual variables */
+/* The remaining BALANCE arguments (SURVEY.md App. A "[verify]"), with the value ASSUMED here and
+ * what it means for this implementation.  None of them is a number the kernels read: each fixes
+ * a branch of HPIPM's algorithm, and the branch written in rti_core.hpp / rti_wave*.hpp / the
+ * oracle is the one named. */
+#define MPC_IPM_T_LAM_MIN 2          /* lam and t are clipped to lam_min / t_min IN THE SOLUTION, i.e. by UPDATE_VAR_QP after
+                                        the step (what Lane::sweep_bu / Wave2::fw do), not only inside Gamma / gamma */
+#define MPC_IPM_COMP_RES_EXIT 1      /* residuals are evaluated at the returned point: the exit test sees true residuals */
+#define MPC_IPM_COMP_RES_PRED 1      /* ... and mu_aff of the predictor is evaluated (needed by cond_pred_corr) */
+#define MPC_IPM_ABS_FORM 0           /* HPIPM iterates on steps (delta form); the kernels carry zeta = z + dz, which is the
+                                        same iteration in exact arithmetic */
+#define MPC_IPM_SQUARE_ROOT_ALG 1    /* square-root Riccati (Cholesky of the stage Hessian); here: LDL^T of H_uu / the scan */
+#define MPC_IPM_WARM_START 0         /* every QP starts from OCP_QP_INIT_VAR's cold start (acados qp_solver_warm_start 0) */
+#define MPC_IPM_VAR_INIT_SCHEME 0    /* the thr0 clipping below, not the safe / heuristic alternatives */
 /* constants inside the algorithm (not arguments) */
 #define MPC_IPM_THR0 1e-1            /* OCP_QP_INIT_VAR: slacks of the cold start are clipped to this */
 #define MPC_IPM_LQ_SWITCH_TOL 1e-5   /* OCP_QP_IPM_DELTA_STEP: lin-system residual above which lq_fact = 1 refactorises */
