@@ -1014,6 +1014,24 @@ static T* pinned_device_ptr(T* host, size_t count) {
     return static_cast<T*>(a.devicePointer);
 }
 
+// Waits for the stream of a latency-path solve (batches of up to 64 instances, ~0.1 ms of device
+// work).  hipStreamSynchronize may put the thread to sleep and the wake-up then lands in the tail of
+// the tick-time distribution (bench.py: p99 = 2.3 x p50 on the driver's box in round 2); polling
+// the stream keeps the thread on its core for the few hundred microseconds a tick can take and falls
+// back to the blocking wait after that.  MPC_SYNC=block restores the plain blocking wait.
+static hipError_t wait_short(hipStream_t st) {
+    static const bool block = [] { const char* e = getenv("MPC_SYNC"); return e && strcmp(e, "block") == 0; }();
+    if (!block) {
+        for (int spin = 0; spin < 20000; ++spin) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        }
+        (void)hipGetLastError();   // hipErrorNotReady is sticky in the last-error slot
+    }
+    return hipStreamSynchronize(st);
+}
+
 // Every shard, even on an error: the work already enqueued on the other shards is waited for
 // before an entry point returns, so the caller's buffers are never written after the return.
 static void sync_all(mpc_batch* h) {
@@ -1493,13 +1511,13 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         //  more around the call cost 10 us of the 110 us a batch = 1 tick took end to end.)
         int rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_SCAN);
         if (rc != 0) { sync_all(h); return rc; }
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        HIPCHK(h, wait_short(s.stream));
         bool pending = false;
         for (int i = 0; i < B; ++i) pending = pending || zst[i] == MPC_STATUS_PENDING;
         if (pending) {
             rc = enqueue_solve(h, s, B, zx0, zyr, zye, zu0, nullptr, nullptr, zst, zit, s.stream, MPC_LAUNCH_LIST_ONLY);
             if (rc != 0) { sync_all(h); return rc; }
-            HIPCHK(h, hipStreamSynchronize(s.stream));
+            HIPCHK(h, wait_short(s.stream));
         }
         if (u0) memcpy(u0, zu0, sizeof(double) * 2 * B);
         if (status) memcpy(status, zst, sizeof(int) * B);
