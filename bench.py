@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal of the multi-rank flow)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -289,6 +290,38 @@ def main():
             hs.close()
             out["e2e_host_ms_per_step"] = dict(e2e, note="mpc_batch_solve on host numpy arrays: H2D of x0/yref/yref_e, the solve, D2H of u0/status/qp_iter; "
                                                "median of 3 warm ticks (u0 returned into pageable memory in both cases)")
+        # ---- the hand-over path under load: a bounds-active, heavy-weight workload (cost weights x 1e4,
+        #      +-0.3 m state box around the start) on which the scan kernel declines instances and the
+        #      sequential list kernel solves them again; never `value` ----
+        if not args.no_stress and world == 1:
+            Bs = min(B, 65536)
+            sps, wls = workload.make(args.variant, Bs)
+            sps = sps.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sps.W), W_e=tuple(1e4 * w for w in sps.W_e))
+            hs = capi.BatchSolver(sps, Bs, devices=[local_rank])
+            d_us = torch.zeros(Bs, 2, dtype=torch.float64, device=dev)
+            d_ss = torch.zeros(Bs, dtype=torch.int32, device=dev)
+            d_is = torch.zeros(Bs, dtype=torch.int32, device=dev)
+            ms, dec, fails, its = [], [], 0, []
+            for t in range(5):
+                x0, yref, yref_e = (a.copy() for a in wls.tick(t))
+                shift = x0[:, :2].copy()
+                x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+                dd = [torch.from_numpy(a).to(dev) for a in (x0, yref, yref_e)]
+                torch.cuda.synchronize()
+                hs.solve_device(Bs, dd[0].data_ptr(), dd[1].data_ptr(), dd[2].data_ptr(), d_us.data_ptr(), 0, 0, d_ss.data_ptr(), d_is.data_ptr())
+                k_ms = hs.last_kernel_ms()
+                torch.cuda.synchronize()
+                if t > 0:
+                    ms.append(k_ms)
+                    dec.append(float(((hs.get_diag(Bs) & 4) != 0).mean()))
+                    fails += int((d_ss.cpu().numpy() != 0).sum())
+                    its.append(float(d_is.cpu().numpy().mean()))
+            hs.close()
+            out["stress_workload"] = {"workload": f"{args.variant} N={N}, cost weights x 1e4, state box +-0.3 m around the start, {Bs} instances, warm ticks 1-4",
+                                      "ms_per_step": float(np.mean(ms)), "solves_per_s": Bs / (1e-3 * float(np.mean(ms))),
+                                      "declined_fraction": float(np.mean(dec)), "mean_qp_iter": float(np.mean(its)), "failed_instances": fails,
+                                      "note": "device time of scan launch + list launch (instances whose scan direction missed the acceptance "
+                                              "threshold are solved again by the sequential kernel with HPIPM's iterative refinement)"}
         # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample, on rank 0 only ----
         if not args.no_cpu_baseline and world == 1:
             from tests import oracle_lib   # the only use of the oracle in this file: the thing timed as the CPU baseline

@@ -218,13 +218,15 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
  *      fired in the reference (the test is made on the corrector's direction here, on the affine one
  *      in HPIPM; the refactorisation itself is not performed, here or in the oracle)
  *   4  wave models: a direction computed with the parallel scans left the stationarity or the
- *      dynamics row of the linear system at 1e-8 or more (absolute, fixed: kScanTolLin in
- *      mpc_amd/csrc/consts.hpp); the instance's QP was solved again from its start by the
+ *      dynamics row of the linear system above the acceptance threshold (dynamics rows: 1e-8;
+ *      stationarity rows: 2e-6 x the smallest cost-Hessian entry, within [1e-8, 2.5e-7] — 1e-8 with
+ *      the reference's weights; mpc_amd/csrc/consts.hpp kScanTolLin); the instance's QP was solved again from its start by the
  *      sequential kernel (sequential Riccati recursion + the refinement of bit 1), launched behind
- *      the scan kernel on the instances it declined.  A scan direction below 1e-8 is taken as is.
+ *      the scan kernel on the instances it declined.  A scan direction below the threshold is taken as is.
  *      Lane model (the cross-check model), SQP_RTI: its sweeps do not refine; an instance whose QP
  *      reached the refinement of bit 1 was handed to the same sequential kernel
- *   8  lane model in full SQP only: the refinement of bit 1 applied and was NOT performed */
+ *   8  lane model in full SQP only: the refinement of bit 1 applied and was NOT performed; the
+ *      instance stops with status MPC_QP_FAILURE (4) at its last accepted iterate */
 #define MPC_DIAG_ITREF 1
 #define MPC_DIAG_LQ 2
 #define MPC_DIAG_SCAN_FALLBACK 4

@@ -55,7 +55,8 @@ struct Consts {
     double nlp_tol;       // exit tolerance on the four NLP residuals (full SQP only)
     // wave model, acceptance tests of the parallel scans (fallback to the sequential recursion):
     double scan_tol_P;    // relative residual of the Riccati equation, stage by stage
-    double scan_tol_lin;  // stationarity residual of the corrector's linear system (absolute)
+    double scan_tol_lin;  // acceptance threshold of a scan direction on the stationarity rows (consts.hpp)
+    double scan_dyn_scale; // scan_tol_lin / 1e-8: the dynamics rows are held against 1e-8
     // uniform values the wave kernels would otherwise compute with vector instructions and keep in
     // vector registers for the whole solve (there is no scalar FP64 unit): wg + reg_prim,
     // we + reg_prim, 1 / (number of one-sided bounds)
@@ -927,7 +928,11 @@ struct Lane : Algebra {
         else if (s.alpha <= c.alpha_min) hs = 2;
         else if (s.mu != s.mu) hs = 3;
         else hs = 0;
-        const bool ok = (hs == 0 || hs == 1);
+        // Full SQP in this model keeps its QPs to itself (host-driven rounds, no list kernel to hand an
+        // instance to): a QP whose direction HPIPM would have refined was solved WITHOUT the refinement,
+        // i.e. off the reference's path.  That is an error, not a result: the instance stops with
+        // QP_FAILURE (4) and MPC_DIAG_ITREF_SKIPPED, its iterate stays at the last accepted one.
+        const bool ok = (hs == 0 || hs == 1) && !(c.sqp && (s.diag & MPC_DIAG_ITREF_SKIPPED));
         const size_t h = (size_t)s.home;
         hm.QPITER[h] = s.kk;
         hm.DIAG[h] = s.diag;

@@ -1076,9 +1076,11 @@ const Opq oq_ = opq();
                 if (SCAN) {
                     // dynamics row: the next stage's dx is what the scan delivered (nx), checked
                     // against this stage's own step
-                    lin_g = amax(lin_g, rb[0] + (ab.B00 * dl[0] + ab.B01 * dl[1] + (dl[2] + ab.a * dl[4])) - nx0);
-                    lin_g = amax(lin_g, rb[1] + (ab.B10 * dl[0] + ab.B11 * dl[1] + (dl[3] + ab.b * dl[4])) - nx1);
-                    lin_g = amax(lin_g, rb[2] + (ab.B20 * dl[0] + ab.B21 * dl[1] + dl[4]) - nx2);
+                    // (scaled so that ONE threshold serves both kinds of rows: consts.hpp kScanTolLin)
+                    const double ds = c.scan_dyn_scale;
+                    lin_g = amax(lin_g, ds * (rb[0] + (ab.B00 * dl[0] + ab.B01 * dl[1] + (dl[2] + ab.a * dl[4])) - nx0));
+                    lin_g = amax(lin_g, ds * (rb[1] + (ab.B10 * dl[0] + ab.B11 * dl[1] + (dl[3] + ab.b * dl[4])) - nx1));
+                    lin_g = amax(lin_g, ds * (rb[2] + (ab.B20 * dl[0] + ab.B21 * dl[1] + dl[4]) - nx2));
                 }
                 if (!is0) {
                     const double lg2 = c.wg[2] * dl[2] + rg[2] + dlam_net[2] - dpm0 + dp0;
@@ -1105,7 +1107,7 @@ const Opq oq_ = opq();
         // the linear system's residual is only ever compared with thresholds: ballots
         o.lin_itref = FINAL ? x.gany(!(lin_g < MPC_IPM_RES_G_MAX)) : false;
         o.lin_lq = FINAL ? x.gany(!(lin_g < MPC_IPM_LQ_SWITCH_TOL)) : false;
-        o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < 1e-8 /* kScanTolLin, consts.hpp */)) : false;
+        o.lin_scan = (FINAL && SCAN) ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
         o.redo_centering = false;
         o.accepted = false;
         if (FINAL) {

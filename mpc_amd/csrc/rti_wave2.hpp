@@ -37,7 +37,6 @@ struct Wave2 : Algebra {
                                 res_m_max = MPC_IPM_RES_M_MAX;
         static constexpr double reg_prim = MPC_IPM_REG_PRIM, lam_min = MPC_IPM_LAM_MIN, t_min = MPC_IPM_T_MIN, tau_min = MPC_IPM_TAU_MIN;
         static constexpr double thr0 = MPC_IPM_THR0, itref_tol_g = MPC_IPM_RES_G_MAX, lq_tol = MPC_IPM_LQ_SWITCH_TOL;
-        static constexpr double scan_tol_lin = 1e-8;   // = kScanTolLin (consts.hpp)
     };
 
     struct Stg {
@@ -1012,9 +1011,11 @@ struct Wave2 : Algebra {
                 if (t.mid) {
                     // dynamics: the next stage's dx is what the scan delivered to it (nx), checked
                     // against this stage's own step
-                    lin_g = amax(lin_g, t.rb[0] + (ab.B00 * d[0] + ab.B01 * d[1] + (d[2] + ab.a * d[4])) - nx[e][0]);
-                    lin_g = amax(lin_g, t.rb[1] + (ab.B10 * d[0] + ab.B11 * d[1] + (d[3] + ab.b * d[4])) - nx[e][1]);
-                    lin_g = amax(lin_g, t.rb[2] + (ab.B20 * d[0] + ab.B21 * d[1] + d[4]) - nx[e][2]);
+                    // (scaled so that ONE threshold serves both kinds of rows: consts.hpp kScanTolLin)
+                    const double ds = c.scan_dyn_scale;
+                    lin_g = amax(lin_g, ds * (t.rb[0] + (ab.B00 * d[0] + ab.B01 * d[1] + (d[2] + ab.a * d[4])) - nx[e][0]));
+                    lin_g = amax(lin_g, ds * (t.rb[1] + (ab.B10 * d[0] + ab.B11 * d[1] + (d[3] + ab.b * d[4])) - nx[e][1]));
+                    lin_g = amax(lin_g, ds * (t.rb[2] + (ab.B20 * d[0] + ab.B21 * d[1] + d[4]) - nx[e][2]));
                     const double lg0 = c.wg[0] * d[0] + t.rg[0] + dlam_net[e][0] + (ab.B00 * dp[0] + ab.B10 * dp[1] + ab.B20 * dp[2]);
                     const double lg1 = c.wg[1] * d[1] + t.rg[1] + dlam_net[e][1] + (ab.B01 * dp[0] + ab.B11 * dp[1] + ab.B21 * dp[2]);
                     lin_g = amax(lin_g, lg0); lin_g = amax(lin_g, lg1);
@@ -1038,16 +1039,18 @@ struct Wave2 : Algebra {
         x.rmax(am);
         x.rsum(as);
         o.alpha = rcp(am[0]); o.s1 = as[0]; o.s2 = as[1];
-        // The scan step is taken only if the stationarity and dynamics rows of the linearised KKT
-        // system (lin_g holds the larger of the two norms) are met to 1e-8 — 100x tighter than /
-        // equal to where HPIPM's refinement loop would stop at once.  The slack and complementarity
+        // The scan step is taken only if the dynamics rows of the linearised KKT system are met to 1e-8
+        // (where HPIPM's refinement loop would stop at once) and the stationarity rows to
+        // c.scan_tol_lin: 1e-8 with the reference's weights, more with heavier ones, never more than a
+        // quarter of HPIPM's 1e-6 (consts.hpp kScanTolLin; lin_g holds the larger of the two norms, the
+        // dynamics rows scaled to the common threshold).  The slack and complementarity
         // rows are met to rounding by construction (dt and dlam are computed FROM those rows, lane by
         // lane, by the same code on either path; adding their norms here was measured at +6 % kernel
         // time) and are checked where refinement can act on them, on the sequential path.
         // A declined instance is solved again by the sequential kernel, which refines as HPIPM does.
         o.lin_itref = false;
         o.lin_lq = FINAL ? x.gany(!(lin_g < K::lq_tol)) : false;
-        o.lin_scan = FINAL ? x.gany(!(lin_g < K::scan_tol_lin)) : false;
+        o.lin_scan = FINAL ? x.gany(!(lin_g < c.scan_tol_lin)) : false;
         o.redo_centering = false;
         o.accepted = false;
         if (FINAL) {
