@@ -214,9 +214,12 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
  *      linearised KKT system at the corrector's direction was not below (res_g_max, res_b_max,
  *      res_d_max, res_m_max), so the system was solved again for the residual with the same
  *      factorisation, up to twice, and the step lengths recomputed (wave models)
- *   2  that residual was above 1e-5: HPIPM's lq_fact = 1 switch to the LQ factorisation may have
- *      fired in the reference (the test is made on the corrector's direction here, on the affine one
- *      in HPIPM; the refactorisation itself is not performed, here or in the oracle)
+ *   2  LQ: HPIPM's lq_fact = 1 switch was PERFORMED (BALANCE mode): the affine direction of the regular
+ *      factorisation left a residual above 1e-5 in the linearised KKT system, so the stage Hessians
+ *      were refactorised from their square roots (HPIPM: LQ of [chol(RSQ) | sqrt(Gamma) | [B A]^T L];
+ *      here: the same triangularisation by Givens rotations) and the QP stayed with that
+ *      factorisation — by the sequential kernel, to which the scan models hand such an instance
+ *      (its scan direction is far above the acceptance threshold of bit 4)
  *   4  wave models: a direction computed with the parallel scans left the stationarity or the
  *      dynamics row of the linear system above the acceptance threshold (dynamics rows: 1e-8;
  *      stationarity rows: 2e-6 x the smallest cost-Hessian entry, within [1e-8, 2.5e-7] — 1e-8 with

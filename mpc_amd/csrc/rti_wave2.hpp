@@ -81,6 +81,7 @@ struct Wave2 : Algebra {
         double alpha, mu, musum;
         bool open;
         bool declined;   // SCAN only: the scan step of this iteration was not accurate enough (see iterate)
+        bool force_lq;   // sequential path: HPIPM's lq_fact = 1 switch has fired, LQ factorisation from now on
     };
 
     __device__ __forceinline__ Wave2(const Consts& c_, int lane_in_group, mc_d2* mc_)
@@ -390,13 +391,14 @@ struct Wave2 : Algebra {
     // US: use the parallel scans (compile-time: the sequential fallback of an iteration is a
     // separate, cold copy of the direction computation, not a run-time switch inside every phase)
     template <bool US>
-    __device__ __forceinline__ void factor_now() {
+    __device__ __forceinline__ void factor_now(bool lq = false) {
         if (US) {
             factor_scan();
         } else {
             double Gam[2][4], gam[2][4];
             barrier_terms(Gam, gam);
-            factor_seq(Gam, gam);
+            if (lq) factor_seq(Gam, gam, FACT_LQ);
+            else factor_seq(Gam, gam, FACT_CHOL);
         }
     }
 
@@ -442,10 +444,79 @@ struct Wave2 : Algebra {
     // Right-hand side of the stage: g5 = gradient part (u0, u1, x, y, psi; barrier terms included),
     // rb = dynamics part.  (The IPM direction passes its residuals, the refinement the residual of
     // the linear system itself.)
+    // `fact`: 0 = right-hand side only, 1 = factorise (value function P, LDL^T of H_uu), 2 = factorise
+    // with HPIPM's LQ variant (lq_stage below): the six numbers passed from stage to stage are then the
+    // lower Cholesky factor S of the value function (P = S S^T) instead of P itself.
+    enum { FACT_NONE = 0, FACT_CHOL = 1, FACT_LQ = 2 };
+    __device__ __forceinline__ static Sym3 sst(const Sym3& S) {   // S S^T, S lower: (00, 10, 11, 20, 21, 22)
+        Sym3 P;
+        P.p00 = S.p00 * S.p00;
+        P.p10 = S.p10 * S.p00;
+        P.p11 = S.p10 * S.p10 + S.p11 * S.p11;
+        P.p20 = S.p20 * S.p00;
+        P.p21 = S.p20 * S.p10 + S.p21 * S.p11;
+        P.p22 = S.p20 * S.p20 + S.p21 * S.p21 + S.p22 * S.p22;
+        return P;
+    }
+    // One stage of OCP_QP_FACT_LQ_SOLVE_KKT_STEP (HPIPM x_ocp_qp_kkt.c; BALANCE mode's lq_fact = 1 switches
+    // to it when the regular factorisation leaves a residual above 1e-5, direction()): the Cholesky
+    // factor L of the stage Hessian H = D + G G^T, D = diag(cost Hessian + reg_prim + barrier terms),
+    // G = [B A]^T S with S the factor of the next stage's value function, is computed from the square
+    // roots — HPIPM: Householder LQ of [D^1/2 | G]; here: diag(D^1/2) updated by the three columns of G
+    // with Givens rotations (the same orthogonal triangularisation, column by column) — so H is
+    // never formed and its condition number never squared.  Out: the gains of the stage in the form the
+    // substitutions use (LDL^T of H_uu, K = -H_uu^-1 H_ux) and S <- L_xx, the factor of this stage's
+    // value function.
+    __device__ __forceinline__ void lq_stage(Stg& t, const double Gam[4], Sym3& S) {
+        const AB8& ab = t.ab;
+        double L[5][5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) L[i][j] = 0.0;
+        L[0][0] = sqrt(c.wgr[0] + Gam[0]); L[1][1] = sqrt(c.wgr[1] + Gam[1]);
+        L[2][2] = sqrt(c.wgr[2] + Gam[2]); L[3][3] = sqrt(c.wgr[3] + Gam[3]); L[4][4] = sqrt(c.wgr[4]);
+        // columns of G = [B A]^T S (rows: v, delta, x, y, psi)
+        double G[3][5];
+        G[0][0] = ab.B00 * S.p00 + ab.B10 * S.p10 + ab.B20 * S.p20; G[1][0] = ab.B10 * S.p11 + ab.B20 * S.p21; G[2][0] = ab.B20 * S.p22;
+        G[0][1] = ab.B01 * S.p00 + ab.B11 * S.p10 + ab.B21 * S.p20; G[1][1] = ab.B11 * S.p11 + ab.B21 * S.p21; G[2][1] = ab.B21 * S.p22;
+        G[0][2] = S.p00; G[1][2] = 0.0; G[2][2] = 0.0;
+        G[0][3] = S.p10; G[1][3] = S.p11; G[2][3] = 0.0;
+        G[0][4] = ab.a * S.p00 + ab.b * S.p10 + S.p20; G[1][4] = ab.b * S.p11 + S.p21; G[2][4] = S.p22;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double* x = G[q];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const double r = sqrt(L[j][j] * L[j][j] + x[j] * x[j]);
+                const double il = rcp(L[j][j]);
+                const double cs = r * il, sn = x[j] * il, ics = rcp(cs);
+                L[j][j] = r;
+#pragma unroll
+                for (int i = j + 1; i < 5; ++i) {
+                    const double lij = (L[i][j] + sn * x[i]) * ics;
+                    x[i] = cs * x[i] - sn * lij;
+                    L[i][j] = lij;
+                }
+            }
+        }
+        t.id0 = rcp(L[0][0] * L[0][0]);
+        t.l10 = L[1][0] * rcp(L[0][0]);
+        t.id1 = rcp(L[1][1] * L[1][1]);
+        // H_ux = L_uu L_xu^T, column by column of the state
+        const double h00 = L[0][0] * L[2][0], h10 = L[1][0] * L[2][0] + L[1][1] * L[2][1];
+        const double h01 = L[0][0] * L[3][0], h11 = L[1][0] * L[3][0] + L[1][1] * L[3][1];
+        const double h02 = L[0][0] * L[4][0], h12 = L[1][0] * L[4][0] + L[1][1] * L[4][1];
+        solve2(t.id0, t.l10, t.id1, h00, h10, t.K00, t.K10);
+        solve2(t.id0, t.l10, t.id1, h01, h11, t.K01, t.K11);
+        solve2(t.id0, t.l10, t.id1, h02, h12, t.K02, t.K12);
+        S.p00 = L[2][2]; S.p10 = L[3][2]; S.p11 = L[3][3]; S.p20 = L[4][2]; S.p21 = L[4][3]; S.p22 = L[4][4];
+    }
     __device__ __forceinline__ void seq_back(Stg& t, const double Gam[4], const double g5[5], const double rb[3],
-                                             bool factorise, Sym3& P, double p[3]) {
+                                             int fact, Sym3& P, double p[3]) {
         if (t.mid) {
-            if (factorise) t.P = P;
+            if (fact == FACT_CHOL) t.P = P;
+            else if (fact == FACT_LQ) t.P = sst(P);
             t.pv[0] = p[0]; t.pv[1] = p[1]; t.pv[2] = p[2];
             const AB8& ab = t.ab;
             const Sym3& Q = t.P;
@@ -454,11 +525,13 @@ struct Wave2 : Algebra {
             const double w2 = Q.p20 * rb[0] + Q.p21 * rb[1] + Q.p22 * rb[2] + p[2];
             const double hu0 = g5[0] + (ab.B00 * w0 + ab.B10 * w1 + ab.B20 * w2);
             const double hu1 = g5[1] + (ab.B01 * w0 + ab.B11 * w1 + ab.B21 * w2);
-            if (factorise) {
+            if (fact == FACT_CHOL) {
                 Gain g;
                 gain(t.P, ab, Gam[0], Gam[1], true, g);
                 set_gain(t, g);
                 if (!t.is0) P = riccati_step(t.P, ab, Gam[2], Gam[3], g);
+            } else if (fact == FACT_LQ) {
+                lq_stage(t, Gam, P);
             }
             solve2(t.id0, t.l10, t.id1, hu0, hu1, t.kff[0], t.kff[1]);
             if (!t.is0) {
@@ -470,11 +543,12 @@ struct Wave2 : Algebra {
                 p[2] = hx2 + (t.K02 * hu0 + t.K12 * hu1);
             }
         } else if (t.isN) {
-            if (factorise) P = terminal_P();
+            if (fact == FACT_CHOL) P = terminal_P();
+            else if (fact == FACT_LQ) { P = zero_P(); P.p00 = sqrt(c.wer[0]); P.p11 = sqrt(c.wer[1]); P.p22 = sqrt(c.wer[2]); }
             p[0] = g5[2]; p[1] = g5[3]; p[2] = g5[4];
         }
     }
-    __device__ __forceinline__ void back_seq(const double Gam[2][4], const double g5[2][5], const double rb[2][3], bool factorise) {
+    __device__ __forceinline__ void back_seq(const double Gam[2][4], const double g5[2][5], const double rb[2][3], int fact) {
         Sym3 Po = terminal_P();
         double po[3] = {0.0, 0.0, 0.0};
         for (int kl = Nl; kl >= 0; --kl) {
@@ -484,30 +558,30 @@ struct Wave2 : Algebra {
                 Sym3 P;
                 P.p00 = sh[0]; P.p10 = sh[1]; P.p11 = sh[2]; P.p20 = sh[3]; P.p21 = sh[4]; P.p22 = sh[5];
                 double p[3] = {sh[6], sh[7], sh[8]};
-                seq_back(s[1], Gam[1], g5[1], rb[1], factorise, P, p);
-                seq_back(s[0], Gam[0], g5[0], rb[0], factorise, P, p);
+                seq_back(s[1], Gam[1], g5[1], rb[1], fact, P, p);
+                seq_back(s[0], Gam[0], g5[0], rb[0], fact, P, p);
                 Po = P; po[0] = p[0]; po[1] = p[1]; po[2] = p[2];
             }
         }
     }
     // the IPM direction's right-hand side: residuals of the stage + barrier terms
-    __device__ __forceinline__ void back_seq_ipm(const double Gam[2][4], const double hup[2][2], const double hxp[2][2], bool factorise) {
+    __device__ __forceinline__ void back_seq_ipm(const double Gam[2][4], const double hup[2][2], const double hxp[2][2], int fact) {
         double g5[2][5], rb[2][3];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             g5[e][0] = hup[e][0]; g5[e][1] = hup[e][1]; g5[e][2] = hxp[e][0]; g5[e][3] = hxp[e][1]; g5[e][4] = s[e].rg[4];
             rb[e][0] = s[e].rb[0]; rb[e][1] = s[e].rb[1]; rb[e][2] = s[e].rb[2];
         }
-        back_seq(Gam, g5, rb, factorise);
+        back_seq(Gam, g5, rb, fact);
     }
-    __device__ __forceinline__ void factor_seq(const double Gam[2][4], const double gam[2][4]) {
+    __device__ __forceinline__ void factor_seq(const double Gam[2][4], const double gam[2][4], int fact = FACT_CHOL) {
         double hup[2][2], hxp[2][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             hup[e][0] = s[e].rg[0] + gam[e][0]; hup[e][1] = s[e].rg[1] + gam[e][1];
             hxp[e][0] = s[e].rg[2] + gam[e][2]; hxp[e][1] = s[e].rg[3] + gam[e][3];
         }
-        back_seq_ipm(Gam, hup, hxp, true);
+        back_seq_ipm(Gam, hup, hxp, fact);
     }
     // one stage of the forward recursion: in dx of stage j, out dx of stage j + 1
     __device__ __forceinline__ void seq_fwd(const Stg& t, const double rb[3], double dx[3], double dl[5]) const {
@@ -936,7 +1010,7 @@ struct Wave2 : Algebra {
         if (US) rhs_scan<false>(hup, hxp);
         else {
             const double Gam0[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            back_seq_ipm(Gam0, hup, hxp, false);
+            back_seq_ipm(Gam0, hup, hxp, FACT_NONE);
         }
     }
 
@@ -1235,7 +1309,6 @@ struct Wave2 : Algebra {
             Resid r;
             double n[4];
             lin_residual(cq, sp, dz, dpi, r, n);
-            if (itref == 0) o.lin_lq = !(fmax(fmax(n[0], n[1]), fmax(n[2], n[3])) <= K::lq_tol);
             if (n[0] < K::res_g_max && n[1] < K::res_b_max && n[2] < K::res_d_max && n[3] < K::res_m_max) break;
             o.lin_itref = true;
             // OCP_QP_SOLVE_KKT_STEP with the residual as right-hand side
@@ -1254,7 +1327,7 @@ struct Wave2 : Algebra {
                 }
             }
             const double Gam0[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            back_seq(Gam0, g5, r.b, false);
+            back_seq(Gam0, g5, r.b, FACT_NONE);
             double nxr[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
             double dzr[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
             fwd_seq(r.b, nxr, dzr);
@@ -1306,6 +1379,31 @@ struct Wave2 : Algebra {
         set_pi(pi);
     }
 
+    // HPIPM's lq_fact = 1 test (OCP_QP_IPM_DELTA_STEP): the residual of the linearised KKT system at the
+    // AFFINE direction the regular factorisation has just produced; any of its four inf-norms above
+    // 1e-5 -> refactorise with LQ and stay with LQ for the rest of this QP.  Sequential path only.
+    __device__ __forceinline__ bool lq_wanted_seq() const {
+        double nx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        double dz[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
+        fwd_seq_ipm(nx, dz);
+        Con cq[2][4];
+        Step sp[2][4];
+        const Opq oq = opq();
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                con_cached(s[e], j, cq[e][j], oq);
+                con_step(cq[e][j], dz[e][j], sp[e][j]);
+            }
+        double dpi[2][3];
+        step_pi(nx, dpi);
+        Resid r;
+        double n[4];
+        lin_residual(cq, sp, dz, dpi, r, n);
+        return !(fmax(fmax(n[0], n[1]), fmax(n[2], n[3])) <= K::lq_tol);
+    }
+
     // ---- the RTI step (Wave::begin / cont / iterate) ----
     __device__ __forceinline__ double nc_inv() const { return c.nc_inv; }
     __device__ __forceinline__ void begin(State& st) {
@@ -1315,6 +1413,7 @@ struct Wave2 : Algebra {
         st.kk = 0;
         st.diag = 0;
         st.declined = false;
+        st.force_lq = false;
     }
     __device__ __forceinline__ bool cont(const State& st) const {
         return st.kk < c.iter_max && st.alpha > K::alpha_min && st.open && !st.declined;
@@ -1324,12 +1423,21 @@ struct Wave2 : Algebra {
     // system (lin_g, what HPIPM's refinement loop tests against 1e-6) is then checked against
     // 1e-8 and a direction that fails is not taken (returns false, nothing changed).
     template <bool US>
-    __device__ __forceinline__ bool direction(const State& st, FwdOut& fc, double& alpha) {
+    __device__ __forceinline__ bool direction(State& st, FwdOut& fc, double& alpha) {
         const double nci = nc_inv();
         long long t0 = 0, t1 = 0;
         (void)t0; (void)t1;
         MPC_PH(0, t0, t0);   // (starts the clock: adds 0)
-        factor_now<US>();
+        if (US) {
+            factor_now<US>();
+        } else {
+            factor_now<false>(st.force_lq);
+            if (!st.force_lq && lq_wanted_seq()) {   // HPIPM lq_fact = 1: switch to the LQ factorisation
+                st.force_lq = true;
+                st.diag |= MPC_DIAG_LQ;
+                factor_now<false>(true);
+            }
+        }
         MPC_PH(0, t0, t1);   // factorisation scan + first right-hand side
         FwdOut fa;
         fw<false, US>(0, 0.0, fa);
@@ -1371,7 +1479,7 @@ struct Wave2 : Algebra {
             direction<false>(st, fc, alpha);
         }
         if (fc.lin_itref) st.diag |= MPC_DIAG_ITREF;
-        if (fc.lin_lq) st.diag |= MPC_DIAG_LQ;
+        if (SCAN && fc.lin_lq) st.diag |= MPC_DIAG_LQ;   // (scan path: the corrector's residual; such a step is declined anyway)
         st.alpha = alpha;
         long long t0 = 0, t1 = 0;
         (void)t0; (void)t1;

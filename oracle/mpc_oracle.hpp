@@ -478,6 +478,85 @@ class OcpQpIpm {
         compute_dlam_dt(rhs, st);
     }
 
+    // OCP_QP_FACT_LQ_SOLVE_KKT_STEP (x_ocp_qp_kkt.c): the same backward recursion with every stage's
+    // Cholesky factor obtained from an LQ factorisation of the stacked square roots
+    //     [ chol(RSQ + reg_prim I) | diag(sqrt(Gamma)) | [B A]^T Lxx(k+1) ]  =  L Q
+    // (BLASFEO dgelqf: Householder reflections), so that the stage Hessian is never formed: L L^T is the
+    // same matrix as in fact_solve_kkt_step, computed without squaring its condition number.  The
+    // columns of L are then signed to a positive diagonal and the right-hand side is solved with the
+    // vector-only recursion (solve_kkt_step), as HPIPM does.  What lq_fact = 1 switches to when the
+    // linear system's residual after the regular factorisation exceeds 1e-5 (delta_step).
+    void fact_lq_solve_kkt_step(const PdVec<T>& rhs, PdVec<T>& st) {
+        using std::sqrt;
+        using std::fabs;
+        compute_Gamma_gamma(rhs, true);
+        constexpr int MC = 2 * NV + NX;   // columns of the stacked matrix
+        for (int k = N_; k >= 0; --k) {
+            const QpStage<T>& s = qp[k];
+            const int nv = s.nv(), nb = s.nb;
+            const int nx1 = k < N_ ? s.nx1 : 0;
+            const int nc = 2 * nv + nx1;
+            T W[NV][MC];
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j < nc; ++j) W[i][j] = T(0.0);
+            // block 1: Cholesky factor of the cost Hessian (+ reg_prim)
+            T Lh[(NV + 1) * NV];
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j <= i; ++j) Lh[i * NV + j] = s.H[i * NV + j];
+            for (int i = 0; i < nv; ++i) Lh[i * NV + i] = Lh[i * NV + i] + T(arg_.reg_prim);
+            potrf_l_mn(nv, nv, Lh);
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j <= i; ++j) W[i][j] = Lh[i * NV + j];
+            // block 2: sqrt of the barrier terms on the bounded variables
+            for (int j = 0; j < nb; ++j) {
+                const int id = s.idxb[j];
+                T g = Gamma_[k][j] + Gamma_[k][nb + j];
+                if (!(g > T(0.0))) g = T(0.0);
+                W[id][nv + id] = sqrt(g);
+            }
+            // block 3: [B A]^T Lxx(k+1)
+            if (k < N_) {
+                const int nu1 = qp[k + 1].nu;
+                const T* L1 = L_[k + 1].data();
+                for (int i = 0; i < nv; ++i)
+                    for (int j = 0; j < nx1; ++j) {
+                        T acc = T(0.0);
+                        for (int q = j; q < nx1; ++q) acc = acc + s.BAt[i * NX + q] * L1[(nu1 + q) * NV + (nu1 + j)];
+                        W[i][2 * nv + j] = acc;
+                    }
+            }
+            // Householder LQ, row by row: after step i row i is (l_i0 .. l_ii 0 .. 0)
+            for (int i = 0; i < nv; ++i) {
+                T nrm2 = T(0.0);
+                for (int j = i; j < nc; ++j) nrm2 = nrm2 + W[i][j] * W[i][j];
+                const T nrm = sqrt(nrm2);
+                if (!(nrm > T(0.0))) continue;
+                const T alpha = W[i][i] > T(0.0) ? -nrm : nrm;
+                T v[MC];
+                for (int j = i; j < nc; ++j) v[j] = W[i][j];
+                v[i] = v[i] - alpha;
+                T vn2 = T(0.0);
+                for (int j = i; j < nc; ++j) vn2 = vn2 + v[j] * v[j];
+                if (!(vn2 > T(0.0))) continue;
+                const T beta = T(2.0) / vn2;
+                for (int r = i; r < nv; ++r) {
+                    T dot = T(0.0);
+                    for (int j = i; j < nc; ++j) dot = dot + W[r][j] * v[j];
+                    const T f = beta * dot;
+                    for (int j = i; j < nc; ++j) W[r][j] = W[r][j] - f * v[j];
+                }
+            }
+            T* M = L_[k].data();
+            for (int i = 0; i <= nv; ++i)
+                for (int j = 0; j < nv; ++j) M[i * NV + j] = T(0.0);
+            for (int j = 0; j < nv; ++j) {
+                const bool neg = W[j][j] < T(0.0);
+                for (int i = j; i < nv; ++i) M[i * NV + j] = neg ? -W[i][j] : W[i][j];
+            }
+        }
+        solve_kkt_step(rhs, st);
+    }
+
     // solve L(0:n,0:n)^T x(0:n) = x(0:n) - L(n:m,0:n)^T x(n:m)   (BLASFEO dtrsv_ltn_mn)
     static void trsv_ltn_mn(int m, int n, const T* Lk, T* x) {
         for (int i = n - 1; i >= 0; --i) {
@@ -654,8 +733,10 @@ class OcpQpIpm {
 
     // OCP_QP_IPM_DELTA_STEP.
     void delta_step() {
-        fact_solve_kkt_step(res_, step_);
         if (arg_.lq_fact == 1 && force_lq_ == 0) {
+            // syrk + potrf; if the affine direction leaves a residual above 1e-5 in any block of the
+            // linearised KKT system: refactorise with LQ, and stay with LQ for the rest of this QP
+            fact_solve_kkt_step(res_, step_);
             res_compute_lin(res_, step_, res_lin_);
             T n[4];
             inf_norm(res_lin_, n);
@@ -663,10 +744,14 @@ class OcpQpIpm {
             for (int i = 0; i < 4; ++i) { double v = to_double(n[i]); if (!(v <= worst)) worst = v; }
             if (!(worst <= stats.max_lin_res_fact)) stats.max_lin_res_fact = worst;
             if (!(worst <= arg_.lq_switch_tol)) {
-                // HPIPM would refactorise with the LQ-based array algorithm here (same
-                // linear system, more accurate).  Recorded, not replicated.
                 stats.lq_switch++;
+                fact_lq_solve_kkt_step(res_, step_);
+                force_lq_ = 1;
             }
+        } else if (arg_.lq_fact == 0) {
+            fact_solve_kkt_step(res_, step_);
+        } else {
+            fact_lq_solve_kkt_step(res_, step_);
         }
         compute_alpha();
         if (arg_.pred_corr == 1) {

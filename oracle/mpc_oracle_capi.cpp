@@ -17,6 +17,7 @@ using namespace mpc_oracle;
 // SURVEY.md §7 hard part 1).  Values <= 0 leave the mode's default in place.
 static double g_tol_override[4] = {0, 0, 0, 0};
 static int g_iter_override = 0;
+static int g_lq_fact_override = -1;   // -1: the mode's value; 0 / 1 / 2 as HPIPM's lq_fact (tests)
 static IpmArg make_arg(const mpc_ocp_spec_t* spec) {
     IpmArg a = ipm_arg_for_mode(spec->hpipm_mode, spec->qp_iter_max);
     if (g_tol_override[0] > 0) a.res_g_max = g_tol_override[0];
@@ -24,6 +25,7 @@ static IpmArg make_arg(const mpc_ocp_spec_t* spec) {
     if (g_tol_override[2] > 0) a.res_d_max = g_tol_override[2];
     if (g_tol_override[3] > 0) a.res_m_max = g_tol_override[3];
     if (g_iter_override > 0) a.iter_max = g_iter_override;
+    if (g_lq_fact_override >= 0) a.lq_fact = g_lq_fact_override;
     return a;
 }
 
@@ -33,6 +35,9 @@ void oracle_set_ipm_override(double res_g, double res_b, double res_d, double re
     g_tol_override[0] = res_g; g_tol_override[1] = res_b; g_tol_override[2] = res_d; g_tol_override[3] = res_m;
     g_iter_override = iter_max;
 }
+
+// HPIPM's lq_fact: 0 Cholesky only, 1 Cholesky with the switch to LQ (BALANCE), 2 LQ always; -1 = the mode's
+void oracle_set_lq_fact(int lq_fact) { g_lq_fact_override = lq_fact; }
 
 int oracle_max_threads(void) {
 #ifdef _OPENMP

@@ -67,6 +67,12 @@ def set_ipm_override(res_g=0.0, res_b=0.0, res_d=0.0, res_m=0.0, iter_max=0):
     lib().oracle_set_ipm_override(res_g, res_b, res_d, res_m, iter_max)
 
 
+def set_lq_fact(lq_fact=-1):
+    """HPIPM's lq_fact in the oracle: 0 Cholesky only, 1 switch to LQ when the residual asks for it
+    (the mode's value), 2 LQ always; -1 restores the mode's value."""
+    lib().oracle_set_lq_fact(int(lq_fact))
+
+
 def vde_forw(x, Sx, Su, u, L=0.0):
     out = np.zeros(18)
     lib().oracle_vde_forw(L, _p(np.ascontiguousarray(x, float)), _p(np.ascontiguousarray(Sx, float)),
