@@ -205,3 +205,35 @@ def test_iteration_statistics(oracle):
     st = r["stats"]
     assert st[:, 2].sum() == 0          # the lq_fact=1 residual test never asks for LQ here
     assert st[:, 5].max() < 1e-9        # linear-system residual after Cholesky Riccati
+
+
+def test_lq_factorisation_equals_cholesky_and_fires_on_heavy_weights(oracle):
+    """HPIPM's LQ variant of the factorisation (lq_fact): (i) forced on every iteration (lq_fact = 2)
+    it reproduces the Cholesky path (lq_fact = 0) to rounding on the regular workloads — same
+    iteration counts, 1e-12; (ii) with the mode's lq_fact = 1 it fires on a heavy-weight, bounds-active
+    workload (the residual test of OCP_QP_IPM_DELTA_STEP), every QP still exits with status 0 and its
+    final residuals below the exit tolerances."""
+    from mpc_amd import workload
+    try:
+        for name in ("mobile_robot", "park"):
+            sp, wl = workload.make(name, 64)
+            x0, yref, yref_e = wl.tick(0)
+            out = {}
+            for lq in (0, 2):
+                oracle.set_lq_fact(lq)
+                r0 = oracle.rti_batch(sp, x0, yref, yref_e)
+                out[lq] = oracle.rti_batch(sp, *wl.tick(1), r0["xtraj"], r0["utraj"])
+            assert np.array_equal(out[0]["qp_iter"], out[2]["qp_iter"])
+            assert np.abs(out[0]["utraj"] - out[2]["utraj"]).max() < 1e-12 and np.abs(out[0]["xtraj"] - out[2]["xtraj"]).max() < 1e-12
+    finally:
+        oracle.set_lq_fact(-1)
+    B = 256
+    sp, wl = workload.make("mobile_robot", B)
+    sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e6 * w for w in sp.W), W_e=tuple(1e6 * w for w in sp.W_e))
+    x0, yref, yref_e = (a.copy() for a in wl.tick(0))
+    shift = x0[:, :2].copy()
+    x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
+    r = oracle.rti_batch(sp, x0, yref, yref_e, want_stats=True)
+    st = r["stats"]
+    assert (st[:, 2] > 0).sum() >= 5 and (st[:, 5] > 1e-5).sum() == (st[:, 2] > 0).sum()   # fired exactly where the residual asked for it
+    assert (r["status"] == 0).all() and (st[:, 1] == 0).all()
