@@ -305,15 +305,78 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 // iterate) writes nothing and is appended to m.REDO.  LIST (with SCAN = false): the sequential kernel
 // over the instances listed in m.REDO — sequential recursions plus HPIPM's iterative refinement —
 // launched right behind the hot kernel with the same grid (blocks beyond the list return at once).
-template <int GW, bool SCAN, bool SQP, bool LIST>
-__global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
+// PERSIST (scan kernels of SQP_RTI batches that need more wavefronts than the chip runs at once): the
+// grid is one wavefront per SIMD slot and every wavefront draws sets of 64 / GW instances from a
+// counter in device memory until none is left, instead of one short-lived workgroup per set — a
+// wavefront slot then never waits for a workgroup to be retired and the next one to be dispatched
+// (measured on 65536 x N = 50: 32 workgroups per slot, the slots idle 7 % of the kernel's span between
+// them).  The counter cleans up after itself: every wavefront makes exactly one fetch that fails, so
+// the fetch that returns n_sets + n_wavefronts - 1 is the last of the launch and puts it back to zero
+// (no memset between solves; a solve recorded in a HIP graph replays).
+// The arguments of k_wave2 as they lie in the kernel-argument segment.  The persistent kernel reads
+// them from there again in every pass of its loop over the sets of instances (scalar loads through an
+// address the optimiser cannot see through), exactly as a freshly launched workgroup does: kept in
+// registers across the loop instead, the ~100 scalar registers of constants and pointers are live
+// through every solve — spilled at the kernel's entry and fetched back lane by lane at every use — and
+// whatever can be computed from them alone is hoisted out of the loop into vector registers on top.
+struct Wave2Args {
+    Consts c;
+    Mem m;
+    int B, sqp_max_iter;
+    WaveIO io;
+};
+typedef const __attribute__((address_space(4))) unsigned* KernArgWords;
+template <class T>
+__device__ __forceinline__ void load_kernarg(T& dst, KernArgWords src, size_t offset) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = src[offset / 4 + i];
+    __builtin_memcpy(&dst, w, sizeof(T));
+}
+
+template <int GW, bool SCAN, bool SQP, bool LIST, bool PERSIST = false>
+__global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg, int sqp_max_iter, WaveIO io_arg) {
     typedef Wave2<GW, SCAN> W;
     static_assert(!(SCAN && LIST), "the list kernel is the sequential one");
+    static_assert(!PERSIST || (SCAN && !SQP && !LIST), "persistent wavefronts: the SQP_RTI scan kernel only");
     constexpr int G = W::PER_BLOCK;
-    const int l = threadIdx.x;
+    __shared__ mc_d2 mc_lds[W::LDS_SLOTS * 64];   // product cache of the scans + parked per-stage state
+  for (;;) {   // (one pass unless PERSIST)
+    Consts c = c_arg;
+    Mem m = m_arg;
+    int B = B_arg;
+    WaveIO io = io_arg;
+    if (PERSIST) {
+        KernArgWords ka = (KernArgWords)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        load_kernarg(c, ka, offsetof(Wave2Args, c));
+        load_kernarg(m, ka, offsetof(Wave2Args, m));
+        load_kernarg(B, ka, offsetof(Wave2Args, B));
+        load_kernarg(io, ka, offsetof(Wave2Args, io));
+    }
+    const int N = c.N;
+    int l = threadIdx.x;
+    // (PERSIST: the lane index is made opaque in every pass, or everything derived from it — stage
+    //  flags, masks, addresses — would be computed once outside the loop and stay live through every solve)
+    if (PERSIST) asm volatile("" : "+v"(l));
     const int g = l / GW, k = l % GW;
     const bool grouped = g < G;   // (GW = 21: lane 63 belongs to no group and carries no instance)
-    const int N = c.N;
+    int blk = (int)blockIdx.x;
+    if (PERSIST) {
+        const int n_sets = (B + G - 1) / G;
+        int v = 0;
+        if (l == 0) v = atomicAdd(&m.REDO[MPC_REDO_WORK], 1);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= n_sets) {
+            if (v == n_sets + (int)gridDim.x - 1 && l == 0) m.REDO[MPC_REDO_WORK] = 0;
+            return;
+        }
+        blk = v;
+    }
+#ifdef MPC_PHASE_CLOCK
+    const long long tk_entry = clock64(), tw_entry = wall_clock64();
+#endif
     size_t i, ic;
     bool inst;
     if (LIST) {
@@ -325,7 +388,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         inst = grouped && slot0 + g < cnt;
         i = ic = (size_t)m.REDO[MPC_REDO_LIST + (inst ? slot0 + g : slot0)];
     } else {
-        i = (size_t)blockIdx.x * G + g;
+        i = (size_t)blk * G + g;
         inst = grouped && i < (size_t)B;
         ic = inst ? i : (size_t)B - 1;
         if (SCAN && blockIdx.x == 0 && l == 0) {
@@ -333,7 +396,6 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
             m.REDO[par ^ 1] = 0; m.REDO[MPC_REDO_PL] = par;
         }
     }
-    __shared__ mc_d2 mc_lds[W::LDS_SLOTS * 64];   // product cache of the scans + parked per-stage state
     W w(c, k, mc_lds + l);
     double* ck[2];
     double* lk[2];
@@ -385,7 +447,12 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         if (SCAN && inst && k == 0 && i < 4096) {
             double* o = m.NLPRES + 4 * (size_t)B + 8 * i;
             for (int q = 0; q < 5; ++q) o[q] = (double)w.ph[q];
-            o[5] = (double)(clock64() - tk0); o[6] = (double)s.kk; o[7] = 0.0;
+            o[5] = (double)(clock64() - tk0); o[6] = (double)s.kk; o[7] = (double)(tk0 - tk_entry);   // o[7]: load + linearise + cold start
+        }
+        // every set of instances: when its wavefront took it up and when the interior-point loop ended (100 MHz wall clock)
+        if (SCAN && l == 0) {
+            double* o = m.NLPRES + 4 * (size_t)B + 8 * 4096 + 2 * (size_t)blk;
+            o[0] = (double)tw_entry; o[1] = (double)wall_clock64();
         }
 #endif
         int hs;
@@ -422,6 +489,7 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
                 }
             }
         }
+        if (PERSIST) continue;   // the next set of instances
         return;
     }
     // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update.
@@ -525,6 +593,8 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c, Mem m, int B, int sqp_ma
         if (io.qp_iter) io.qp_iter[i] = qp_it;
         io.u0[2 * i] = ck[0][C_U + 0]; io.u0[2 * i + 1] = ck[0][C_U + 1];
     }
+    return;
+  }
 }
 
 // Full SQP only (spec.sqp_max_iter > 1; BASELINE config 5): the head of one SQP iteration.
@@ -1196,6 +1266,22 @@ enum { MPC_LAUNCH_BOTH = 0, MPC_LAUNCH_SCAN = 1, MPC_LAUNCH_LIST_ONLY = 2 };
 // Lanes per OCP of the two-stages-per-lane kernels: N + 1 stages need ceil((N + 1) / 2) lanes.
 // 16 / 32 / 64 lanes align with the DPP rows; 21 lanes put three OCPs of 33..42 stages (the
 // reference's N = 40 variants) into a wavefront instead of two.
+// Wavefront slots of the current device for the persistent scan kernels (k_wave2<.., PERSIST>): four
+// per CU — one wavefront per SIMD is what 512 registers and 40 KB of LDS allow — or 0 = one workgroup
+// per set of instances (MPC_PERSIST=0, or the device could not be queried).
+static int persistent_slots() {
+    static const bool off = [] { const char* e = getenv("MPC_PERSIST"); return e && strcmp(e, "0") == 0; }();
+    if (off) return 0;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = -1; }
+        cus[dev] = n;
+    }
+    return cus[dev] > 0 ? 4 * cus[dev] : 0;
+}
 static int wave2_group_width(int N) { return N + 1 <= 32 ? 16 : N + 1 <= 42 ? 21 : N + 1 <= 64 ? 32 : 64; }
 static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
                         bool one_stage_per_lane = false, bool two_stages_per_lane = false, int part = MPC_LAUNCH_BOTH) {
@@ -1237,7 +1323,11 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
         if (seq) {                                                                                                        \
             hipLaunchKernelGGL((k_wave2<GW_, false, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);         \
         } else {                                                                                                          \
-            if (part != MPC_LAUNCH_LIST_ONLY)                                                                             \
+            const int slots = persistent_slots();                                                                         \
+            if (part == MPC_LAUNCH_LIST_ONLY) {                                                                           \
+            } else if (slots > 0 && (int)grd.x > slots && GW_ != 64)                                                      \
+                hipLaunchKernelGGL((k_wave2<GW_ == 64 ? 32 : GW_, true, false, false, true>), dim3(slots), blk, 0, st, c, m, n, sqp_max_iter, wio); \
+            else                                                                                                          \
                 hipLaunchKernelGGL((k_wave2<GW_, true, false, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);      \
             MPC_LAUNCH_LIST();                                                                                            \
         }                                                                                                                 \

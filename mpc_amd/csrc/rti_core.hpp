@@ -116,7 +116,7 @@ struct Mem {
     // nothing declined) leaves the side unchanged — its counter is then still zero.
     int* REDO;
 };
-enum { MPC_REDO_LIST = 64, MPC_REDO_PS = 2, MPC_REDO_PL = 3 };
+enum { MPC_REDO_LIST = 64, MPC_REDO_PS = 2, MPC_REDO_PL = 3, MPC_REDO_WORK = 4 };   // WORK: the work counter of persistent wavefronts (mpc_batch.hip k_wave2)
 enum : int { MPC_CAP = 8, C_X = 0, C_U = 3, C_PI = 5 };
 
 // MPC_DIAG_ITREF / MPC_DIAG_LQ / MPC_DIAG_SCAN_FALLBACK / MPC_DIAG_ITREF_SKIPPED: include/mpc_batch.h

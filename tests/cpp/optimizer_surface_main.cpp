@@ -15,6 +15,11 @@ using namespace mpc_amd;
 static void p3(const char* tag, const Vector3d& v) { printf("%s %.17g %.17g %.17g\n", tag, v[0], v[1], v[2]); }
 
 int main(int argc, char** argv) {
+#ifdef MPC_HAVE_EIGEN
+    fprintf(stderr, "vector types: <Eigen/Dense>\n");
+#else
+    fprintf(stderr, "vector types: stand-in\n");
+#endif
     if (argc < 3) { fprintf(stderr, "usage: %s state_refs.txt input_refs.txt\n", argv[0]); return 2; }
     const MatrixXd s = Optimizer::loadTxt(argv[1]);
     const MatrixXd u = Optimizer::loadTxt(argv[2]);

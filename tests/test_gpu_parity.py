@@ -482,7 +482,14 @@ def test_cpp_optimizer_surface():
     uf = os.path.join(here, "golden", "input_refs_path150_head.txt")
     out = subprocess.run([exe, sf, uf], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "Invalid mode" in out.stderr
+    assert "Invalid mode" in out.stderr and "vector types: stand-in" in out.stderr
+    # the same program compiled through the header's MPC_HAVE_EIGEN branch (public types Eigen::Vector3d /
+    # VectorXd / MatrixXd, column-major) against tests/cpp/mock_eigen — a mock of the Eigen subset the
+    # header uses, this image has no Eigen: every printed number must be the same
+    out_e = subprocess.run([exe + "_eigenmock", sf, uf], capture_output=True, text=True, timeout=120)
+    assert out_e.returncode == 0 and "vector types: <Eigen/Dense>" in out_e.stderr
+    keep = lambda txt: [l for l in txt.strip().splitlines() if "estimation time" not in l and not l.startswith("time")]
+    assert keep(out_e.stdout) == keep(out.stdout)
     lines = out.stdout.strip().splitlines()
     assert sum("estimation time" in l for l in lines) == 6     # computeStats prints mean / max / min tick time, twice here
     rows = [l.split() for l in lines if "estimation time" not in l]
