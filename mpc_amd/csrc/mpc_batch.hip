@@ -123,13 +123,61 @@ struct WaveIO {
     int* qp_iter;          // [B]
 };
 
-template <class X, bool SCAN, bool SQP>
-__global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int sqp_max_iter, WaveIO io) {
+// The arguments of k_wave / k_wave2 as they lie in the kernel-argument segment.  The persistent kernel reads
+// them from there again in every pass of its loop over the sets of instances (scalar loads through an
+// address the optimiser cannot see through), exactly as a freshly launched workgroup does: kept in
+// registers across the loop instead, the ~100 scalar registers of constants and pointers are live
+// through every solve — spilled at the kernel's entry and fetched back lane by lane at every use — and
+// whatever can be computed from them alone is hoisted out of the loop into vector registers on top.
+struct Wave2Args {
+    Consts c;
+    Mem m;
+    int B, sqp_max_iter;
+    WaveIO io;
+};
+typedef const __attribute__((address_space(4))) unsigned* KernArgWords;
+template <class T>
+__device__ __forceinline__ void load_kernarg(T& dst, KernArgWords src, size_t offset) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = src[offset / 4 + i];
+    __builtin_memcpy(&dst, w, sizeof(T));
+}
+
+// PERSIST: see k_wave2.
+template <class X, bool SCAN, bool SQP, bool PERSIST = false>
+__global__ __launch_bounds__(X::THREADS) void k_wave(Consts c_arg, Mem m_arg, int B_arg, int sqp_max_iter, WaveIO io_arg) {
+    static_assert(!PERSIST || (SCAN && !SQP && X::THREADS == 64), "persistent wavefronts: the SQP_RTI scan kernel, one wavefront per workgroup");
     constexpr int G = X::PER_BLOCK;
     constexpr int GW = X::LANES;
-    const int l = threadIdx.x;
+  for (;;) {   // (one pass unless PERSIST)
+    Consts c = c_arg;
+    Mem m = m_arg;
+    int B = B_arg;
+    WaveIO io = io_arg;
+    int l = threadIdx.x;
+    int blk = (int)blockIdx.x;
+    if (PERSIST) {
+        KernArgWords ka = (KernArgWords)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        load_kernarg(c, ka, offsetof(Wave2Args, c));
+        load_kernarg(m, ka, offsetof(Wave2Args, m));
+        load_kernarg(B, ka, offsetof(Wave2Args, B));
+        load_kernarg(io, ka, offsetof(Wave2Args, io));
+        asm volatile("" : "+v"(l));
+        const int n_sets = (B + G - 1) / G;
+        int v = 0;
+        if (l == 0) v = atomicAdd(&m.REDO[MPC_REDO_WORK], 1);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= n_sets) {
+            if (v == n_sets + (int)gridDim.x - 1 && l == 0) m.REDO[MPC_REDO_WORK] = 0;
+            return;
+        }
+        blk = v;
+    }
     const int g = l / GW, k = l % GW;
-    const size_t i = (size_t)blockIdx.x * G + g;
+    const size_t i = (size_t)blk * G + g;
     const int N = c.N;
     const bool inst = i < (size_t)B;
     const size_t ic = inst ? i : (size_t)B - 1;
@@ -137,7 +185,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     double* ck = m.cap + ((size_t)ic * (N + 1) + kcl) * MPC_CAP;   // this lane's capsule line
     X xpol = make_policy<X>(l);
     Wave<X, SCAN> w(c, k, xpol);   // (no LDS: the product cache of the scans lives in registers, rti_wave.hpp Mc)
-    if (SCAN && blockIdx.x == 0 && l == 0) {   // this launch's list counter (Mem::REDO)
+    if (SCAN && blockIdx.x == 0 && l == 0) {   // this launch's list counter (Mem::REDO; the same values in every pass)
         const int par = m.REDO[MPC_REDO_PS];
         m.REDO[par ^ 1] = 0; m.REDO[MPC_REDO_PL] = par;
     }
@@ -180,12 +228,13 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 #pragma unroll
             for (int q = 0; q < 3; ++q) xi[q] = w.z[2 + q];
         }
-        if (!on) return;
+        if (!on) { if (PERSIST) continue; return; }
         if (SCAN && s.declined) {   // nothing is written: the sequential kernel redoes this QP (k_wave2<.., LIST>)
             if (k == 0) {
                 m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
                 if (io.status) io.status[i] = MPC_STATUS_PENDING;
             }
+            if (PERSIST) continue;
             return;
         }
         if (k == 0) {
@@ -204,6 +253,7 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
                 for (int q = 0; q < 3; ++q) ck[C_PI + q] = w.pi[q];
             }
         }
+        if (PERSIST) continue;
         return;
     }
     // ---- full SQP (acados ocp_nlp_sqp.c order): linearise, residuals, exit test, QP, update;
@@ -296,6 +346,8 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
     if (io.status) io.status[i] = status;
     if (io.qp_iter) io.qp_iter[i] = qp_it;
     io.u0[2 * i] = ck[C_U + 0]; io.u0[2 * i + 1] = ck[C_U + 1];   // this lane's own line of the capsule
+    return;
+  }
 }
 
 // The same step with TWO stages per lane (rti_wave2.hpp): lane k of a GW-lane group owns stages 2k
@@ -313,28 +365,6 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c, Mem m, int B, int
 // them).  The counter cleans up after itself: every wavefront makes exactly one fetch that fails, so
 // the fetch that returns n_sets + n_wavefronts - 1 is the last of the launch and puts it back to zero
 // (no memset between solves; a solve recorded in a HIP graph replays).
-// The arguments of k_wave2 as they lie in the kernel-argument segment.  The persistent kernel reads
-// them from there again in every pass of its loop over the sets of instances (scalar loads through an
-// address the optimiser cannot see through), exactly as a freshly launched workgroup does: kept in
-// registers across the loop instead, the ~100 scalar registers of constants and pointers are live
-// through every solve — spilled at the kernel's entry and fetched back lane by lane at every use — and
-// whatever can be computed from them alone is hoisted out of the loop into vector registers on top.
-struct Wave2Args {
-    Consts c;
-    Mem m;
-    int B, sqp_max_iter;
-    WaveIO io;
-};
-typedef const __attribute__((address_space(4))) unsigned* KernArgWords;
-template <class T>
-__device__ __forceinline__ void load_kernarg(T& dst, KernArgWords src, size_t offset) {
-    static_assert(sizeof(T) % 4 == 0, "whole words");
-    unsigned w[sizeof(T) / 4];
-#pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = src[offset / 4 + i];
-    __builtin_memcpy(&dst, w, sizeof(T));
-}
-
 template <int GW, bool SCAN, bool SQP, bool LIST, bool PERSIST = false>
 __global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg, int sqp_max_iter, WaveIO io_arg) {
     typedef Wave2<GW, SCAN> W;
@@ -1313,6 +1343,9 @@ static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, 
         const dim3 grd((n + X_::PER_BLOCK - 1) / X_::PER_BLOCK), blk(X_::THREADS);                                        \
         if (part == MPC_LAUNCH_LIST_ONLY) {                                                                               \
         } else if (sqp) hipLaunchKernelGGL((k_wave<X_, true, true>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);        \
+        else if (persistent_slots() > 0 && (int)grd.x > persistent_slots())                          \
+            hipLaunchKernelGGL((k_wave<X_, true, false, true>), dim3(persistent_slots()), blk, 0, st, \
+                               c, m, n, sqp_max_iter, wio);                                                               \
         else hipLaunchKernelGGL((k_wave<X_, true, false>), grd, blk, 0, st, c, m, n, sqp_max_iter, wio);                  \
         MPC_LAUNCH_LIST();                                                                                                \
     } while (0)

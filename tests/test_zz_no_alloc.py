@@ -136,7 +136,8 @@ def test_static_call_captured_in_a_graph_replays_like_a_handle():
     counts from zero like a fresh call.  Against a handle making the same calls: bit for bit, three
     replays in a row."""
     torch = pytest.importorskip("torch")
-    B = 2000
+    B = 4000   # 2000 sets of two instances: more than the chip's 1024 wavefront slots, i.e. the persistent scan kernel,
+    #            whose work counter must put itself back to zero for the next replay
     sp, wl = workload.make("mobile_robot", B)
     x0, yref, yref_e = (a.copy() for a in wl.tick(0))
     shift = x0[:, :2].copy()

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "ab", "phase_clock.so")
 if not os.path.exists(lib) or "--build" in sys.argv:
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMPC_PHASE_CLOCK", "-shared",
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMPC_PHASE_CLOCK", "-mllvm", "-disable-machine-licm", "-shared",
                     "-o", lib, "mpc_batch.hip"], cwd=os.path.join(ROOT, "mpc_amd", "csrc"), check=True)
 if "--build" in sys.argv:
     sys.exit(0)
@@ -49,7 +49,7 @@ print(f"  load + linearise + cold start (before the loop) {d[:, 7].mean():10.0f}
 w = np.asarray(res).reshape(-1)[4 * B + 8 * 4096:4 * B + 8 * 4096 + 2 * (B // 2)].reshape(-1, 2)
 t0, t1 = w[:, 0].min(), w[:, 1].max()
 span = t1 - t0
-busy = (w[:, 1] - w[:, 0]).sum() / (1024 * span)
+busy = (w[:, 1] - w[:, 0]).sum() / (1024 * span)   # (1024 = the SIMD slots of 256 CUs)
 last_start = w[:, 0].max()
 order = np.sort(w[:, 1])
 print(f"kernel span {span / 100:.1f} us (100 MHz clock); wavefront-busy share of 1024 slots {100 * busy:.1f} %")
