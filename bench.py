@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # Counter-derived figures of the dominant kernel (HBM bytes moved, FP64 flops executed per launch)
 # come from the rocprofv3 passes committed under profiles/; the summary names the sources it was
 # taken on, and the bench line says `stale: true` when the kernel sources have changed since.
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02", "summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03", "summary.json")
 KERNEL_SOURCES = ("mpc_amd/csrc/mpc_batch.hip", "mpc_amd/csrc/rti_wave2.hpp", "mpc_amd/csrc/rti_wave.hpp",
                   "mpc_amd/csrc/rti_core.hpp", "mpc_amd/csrc/consts.hpp", "include/mpc_hpipm_args.h")
 

@@ -8,7 +8,7 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-latency --no-e2e"
+BENCH="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-latency --no-e2e --no-stress"
 run() {  # name, rocprof args...
     local name=$1; shift
     timeout -s KILL 170 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/$name.log"; return 1; }

@@ -81,6 +81,6 @@ hc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
 summary["commit"] = open(hc).read().strip() if os.path.exists(hc) else None
 summary["batch"] = 65536
 summary["horizon"] = 50
-summary["command"] = "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-latency --no-e2e (one rocprofv3 run per counter group, tools/prof.sh)"
+summary["command"] = "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-latency --no-e2e --no-stress (one rocprofv3 run per counter group, tools/prof.sh)"
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernel_stats_top"}, indent=1))
