@@ -215,7 +215,7 @@ def main():
         ach_tf = flops_launch / (l_ms * 1e-3) / 1e12
         ach_gbs = bytes_launch / (l_ms * 1e-3) / 1e9
         prof = load_profile_summary(B, N)
-        roof = {"bound": "fp64_vector", "kernel": "k_wave2<32,scan,rti>" if 32 < N + 1 <= 64 else "wave-model solve kernel",
+        roof = {"bound": "fp64_vector", "kernel": "k_wave2<32,scan,rti,persistent>" if 42 < N + 1 <= 64 and B > 16384 else "wave-model solve kernel",
                 "launch_ms": l_ms, "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                 # the same duration priced with the two smaller counts: operations on non-structural
