@@ -321,7 +321,8 @@ def main():
                                       "ms_per_step": float(np.mean(ms)), "solves_per_s": Bs / (1e-3 * float(np.mean(ms))),
                                       "declined_fraction": float(np.mean(dec)), "mean_qp_iter": float(np.mean(its)), "failed_instances": fails,
                                       "note": "device time of scan launch + list launch (instances whose scan direction missed the acceptance "
-                                              "threshold are solved again by the sequential kernel with HPIPM's iterative refinement)"}
+                                              "threshold carry on from that iteration in the sequential kernel, which also performs HPIPM's iterative "
+                                              "refinement and LQ refactorisation)"}
         # ---- CPU baseline: the oracle (a port, not acados) on a bounded sample, on rank 0 only ----
         if not args.no_cpu_baseline and world == 1:
             from tests import oracle_lib   # the only use of the oracle in this file: the thing timed as the CPU baseline

@@ -223,17 +223,24 @@ int mpc_batch_get_sqp(mpc_batch_t* h, int B, int* sqp_iter, double* res4);
  *   4  wave models: a direction computed with the parallel scans left the stationarity or the
  *      dynamics row of the linear system above the acceptance threshold (dynamics rows: 1e-8;
  *      stationarity rows: 2e-6 x the smallest cost-Hessian entry, within [1e-8, 2.5e-7] — 1e-8 with
- *      the reference's weights; mpc_amd/csrc/consts.hpp kScanTolLin); the instance's QP was solved again from its start by the
+ *      the reference's weights; mpc_amd/csrc/consts.hpp kScanTolLin); the instance went to the
  *      sequential kernel (sequential Riccati recursion + the refinement of bit 1), launched behind
  *      the scan kernel on the instances it declined.  A scan direction below the threshold is taken as is.
  *      Lane model (the cross-check model), SQP_RTI: its sweeps do not refine; an instance whose QP
  *      reached the refinement of bit 1 was handed to the same sequential kernel
  *   8  lane model in full SQP only: the refinement of bit 1 applied and was NOT performed; the
- *      instance stops with status MPC_QP_FAILURE (4) at its last accepted iterate */
+ *      instance stops with status MPC_QP_FAILURE (4) at its last accepted iterate
+ *  16  with bit 4, SQP_RTI handles: the sequential kernel CARRIED ON from the interior-point iterate of
+ *      the declined iteration (the iterations before it are the scan kernel's, all below the
+ *      threshold) instead of solving the QP again from HPIPM's cold start.  Not set: from the cold
+ *      start — full-SQP handles, instances handed over by the lane model, handles created with
+ *      MPC_RESUME=0 in the environment, and mpc_batch_solve_static (its array has no room for the
+ *      iterates: 192 B per stage).  Either way status and iteration count are HPIPM's */
 #define MPC_DIAG_ITREF 1
 #define MPC_DIAG_LQ 2
 #define MPC_DIAG_SCAN_FALLBACK 4
 #define MPC_DIAG_ITREF_SKIPPED 8
+#define MPC_DIAG_RESUMED 16
 int mpc_batch_get_diag(mpc_batch_t* h, int B, int* diag);
 
 /* Execution model of the solve kernels (no counterpart in the reference; results agree to

@@ -120,6 +120,7 @@ inline Mem make_mem(int* islab, size_t capacity, int N) {
     m.NLPRES = reinterpret_cast<double*>(islab + 6 * S);   // S is a multiple of 64: 8-byte aligned
     m.cap = nullptr; m.lam = nullptr; m.u0 = nullptr;
     m.REDO = islab + 14 * S;   // 2 S >= 64 + S ints
+    m.IPM = nullptr; m.ipm_slots = 0;
     return m;
 }
 // element (instance i, stage k, row r) as an index in doubles from the slab start

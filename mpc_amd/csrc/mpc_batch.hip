@@ -229,11 +229,15 @@ __global__ __launch_bounds__(X::THREADS) void k_wave(Consts c_arg, Mem m_arg, in
             for (int q = 0; q < 3; ++q) xi[q] = w.z[2 + q];
         }
         if (!on) { if (PERSIST) continue; return; }
-        if (SCAN && s.declined) {   // nothing is written: the sequential kernel redoes this QP (k_wave2<.., LIST>)
+        if (SCAN && s.declined) {   // nothing is written: the sequential kernel takes this QP over (k_wave2<.., LIST>)
+            int pos = -1;
             if (k == 0) {
-                m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
+                pos = atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1);
+                m.REDO[MPC_REDO_LIST + pos] = (int)i | (pos < m.ipm_slots ? MPC_REDO_SAVED : 0);
                 if (io.status) io.status[i] = MPC_STATUS_PENDING;
             }
+            pos = __shfl(pos, g * GW);   // the group's first lane (all lanes of a declined group are here)
+            if (pos < m.ipm_slots) w.save_ipm(m.IPM + (size_t)pos * ((size_t)(N + 1) * MPC_IPM_STAGE + MPC_IPM_HEAD), s);
             if (PERSIST) continue;
             return;
         }
@@ -409,6 +413,8 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg
 #endif
     size_t i, ic;
     bool inst;
+    int list_pos = 0;
+    bool resumed = false;
     if (LIST) {
         const int par = m.REDO[MPC_REDO_PL];   // this solve's list counter (Mem::REDO)
         const int cnt = m.REDO[par];
@@ -416,7 +422,10 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg
         const int slot0 = (int)blockIdx.x * G;
         if (slot0 >= cnt) return;
         inst = grouped && slot0 + g < cnt;
-        i = ic = (size_t)m.REDO[MPC_REDO_LIST + (inst ? slot0 + g : slot0)];
+        list_pos = inst ? slot0 + g : slot0;
+        const int entry = m.REDO[MPC_REDO_LIST + list_pos];
+        resumed = !SQP && inst && (entry & MPC_REDO_SAVED) != 0;   // its interior-point iterate waits in Mem::IPM
+        i = ic = (size_t)(entry & ~MPC_REDO_SAVED);
     } else {
         i = (size_t)blk * G + g;
         inst = grouped && i < (size_t)B;
@@ -466,6 +475,8 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg
         const long long tk0 = clock64();
 #endif
         w.begin(s);
+        const size_t ipm_stride = (size_t)(N + 1) * MPC_IPM_STAGE + MPC_IPM_HEAD;
+        if (LIST && resumed) w.load_ipm(m.IPM + (size_t)list_pos * ipm_stride, s);   // carry on from the iteration the scan kernel declined
         for (;;) {
             const bool go = inst && w.cont(s);
             if (!w.x.any(go)) break;
@@ -492,13 +503,19 @@ __global__ __launch_bounds__(64) void k_wave2(Consts c_arg, Mem m_arg, int B_arg
         else hs = 0;
         const bool ok = (hs == 0 || hs == 1);
         status = ok ? 0 : 4;
-        const bool redo = SCAN && s.declined;   // nothing is written; the list kernel redoes this QP
-        if (redo && inst && k == 0) {
-            m.REDO[MPC_REDO_LIST + atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1)] = (int)i;
-            if (io.status) io.status[i] = MPC_STATUS_PENDING;
+        const bool redo = SCAN && s.declined;   // nothing is written; the list kernel takes this QP over
+        if (SCAN && w.x.any(redo && inst)) {
+            int pos = -1;
+            if (redo && inst && k == 0) {
+                pos = atomicAdd(&m.REDO[m.REDO[MPC_REDO_PS]], 1);
+                m.REDO[MPC_REDO_LIST + pos] = (int)i | (pos < m.ipm_slots ? MPC_REDO_SAVED : 0);
+                if (io.status) io.status[i] = MPC_STATUS_PENDING;
+            }
+            pos = __shfl(pos, g * GW);   // the group's first lane
+            if (redo && inst && pos < m.ipm_slots) w.save_ipm(m.IPM + (size_t)pos * ipm_stride, s);
         }
         if (inst && k == 0 && !redo) {
-            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag | (LIST ? MPC_DIAG_SCAN_FALLBACK : 0); m.STATUS[i] = status;
+            m.QPITER[i] = s.kk; m.DIAG[i] = s.diag | w.wdiag | (LIST ? MPC_DIAG_SCAN_FALLBACK : 0) | (resumed ? MPC_DIAG_RESUMED : 0); m.STATUS[i] = status;
             if (io.status) io.status[i] = status;
             if (io.qp_iter) io.qp_iter[i] = s.kk;
             // on a QP failure the previous u_0 stays in force
@@ -1004,6 +1021,7 @@ struct Shard {
     int sqp_rounds = 0;  // QP rounds of the last full-SQP solve (lane model)
     // allocated by mpc_batch_create: the capsules, the small per-instance arrays, u0
     double* capbuf = nullptr;  // Mem::cap
+    double* ipmbuf = nullptr;  // Mem::IPM
     double* lambuf = nullptr;  // Mem::lam (full-SQP handles only)
     int* islab = nullptr;
     double* d_u0 = nullptr;    // [S][2] u_0 of the last solve when the caller passes none
@@ -1072,7 +1090,7 @@ static void free_shard(Shard& s) {
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     (void)hipFree(s.slab); (void)hipFree(s.slab2); (void)hipFree(s.islab); (void)hipFree(s.phase_ints);
-    (void)hipFree(s.capbuf); (void)hipFree(s.lambuf); (void)hipFree(s.d_u0);
+    (void)hipFree(s.capbuf); (void)hipFree(s.lambuf); (void)hipFree(s.d_u0); (void)hipFree(s.ipmbuf);
     (void)hipFree(s.s_x0); (void)hipFree(s.s_yref); (void)hipFree(s.s_yrefe); (void)hipFree(s.s_u0);
     (void)hipFree(s.s_xt); (void)hipFree(s.s_ut); (void)hipFree(s.s_pi); (void)hipFree(s.s_mask);
     if (s.z_in) (void)hipHostFree(s.z_in);
@@ -1311,6 +1329,12 @@ static int persistent_slots() {
         cus[dev] = n;
     }
     return cus[dev] > 0 ? 4 * cus[dev] : 0;
+}
+// MPC_RESUME=0 when a handle is created: no Mem::IPM pool, the list kernel solves declined instances
+// again from the cold start — what the no-allocation entry point does; A/B runs and tests
+static bool ipm_pool_enabled() {
+    const char* e = getenv("MPC_RESUME");
+    return !(e && strcmp(e, "0") == 0);
 }
 static int wave2_group_width(int N) { return N + 1 <= 32 ? 16 : N + 1 <= 42 ? 21 : N + 1 <= 64 ? 32 : 64; }
 static void launch_wave(const Consts& c, const Mem& m, int n, int sqp_max_iter, const WaveIO& wio, bool seq, hipStream_t st,
@@ -1564,6 +1588,15 @@ int mpc_batch_create(mpc_batch_t** out, const mpc_ocp_spec_t* spec, int capacity
             }
             DEVALLOC(h, s, s.d_u0, sizeof(double) * 2 * s.S);
             HIPCHK(h, hipMemsetAsync(s.d_u0, 0, sizeof(double) * 2 * s.S, s.stream));
+            if (spec->sqp_max_iter <= 1 && ipm_pool_enabled()) {
+                // Mem::IPM: a record for every capsule — with fewer, which of the declined instances get one
+                // would depend on the order of their atomics and results would not repeat from run to run
+                const int slots = capa;
+                const size_t pb = (size_t)slots * ((size_t)(N + 1) * MPC_IPM_STAGE + MPC_IPM_HEAD) * sizeof(double);
+                DEVALLOC(h, s, s.ipmbuf, pb);
+                s.mem.IPM = s.ipmbuf;
+                s.mem.ipm_slots = slots;
+            }
             s.mem2 = s.mem;
             {
                 const size_t Z = capa < MPC_ZEROCOPY_MAX ? capa : MPC_ZEROCOPY_MAX;

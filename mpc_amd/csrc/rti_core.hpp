@@ -115,7 +115,16 @@ struct Mem {
     // launches of a solve are ordered on one stream.  A list launch that is skipped (latency path,
     // nothing declined) leaves the side unchanged — its counter is then still zero.
     int* REDO;
+    // Interior-point state of declined instances (RTI handles): a scan kernel that declines an instance
+    // parks the iterate of the iteration it could not certify — per stage z 5, pi 3, lam 8, t 8, and per
+    // instance {iterations done, last step length, diag bits} — in slot n of this pool, n = the
+    // instance's position in the list, and marks the list entry (MPC_REDO_SAVED); the list kernel then
+    // carries on from that iteration instead of solving the QP again from its cold start.  Entries
+    // beyond ipm_slots (or with no pool at all: the no-allocation entry point) are solved from the start.
+    double* IPM;         // [ipm_slots][(N + 1) * MPC_IPM_STAGE + MPC_IPM_HEAD]
+    int ipm_slots;
 };
+enum { MPC_IPM_STAGE = 24, MPC_IPM_HEAD = 8, MPC_REDO_SAVED = (int)0x40000000 };
 enum { MPC_REDO_LIST = 64, MPC_REDO_PS = 2, MPC_REDO_PL = 3, MPC_REDO_WORK = 4 };   // WORK: the work counter of persistent wavefronts (mpc_batch.hip k_wave2)
 enum : int { MPC_CAP = 8, C_X = 0, C_U = 3, C_PI = 5 };
 

@@ -1151,6 +1151,23 @@ const Opq oq_ = opq();
         s.diag = 0;
         s.declined = false;
     }
+    // Mem::IPM: park the interior-point iterate of a declined instance (nothing of the declined iteration
+    // has touched it) for the list kernel, which carries on from this iteration (Wave2::load_ipm).
+    // `slot`: the instance's record, (N + 1) stages of MPC_IPM_STAGE doubles + the head.
+    __device__ __forceinline__ void save_ipm(double* slot, const State& s) const {
+        if (!act) return;
+        double* r = slot + (size_t)k * MPC_IPM_STAGE;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = z[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[5 + q] = pi[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { r[8 + q] = bn.lam[q]; r[16 + q] = bn.t[q]; }
+        if (is0) {
+            double* hd = slot + (size_t)(N + 1) * MPC_IPM_STAGE;
+            hd[0] = (double)s.kk; hd[1] = s.alpha; hd[2] = (double)s.diag;
+        }
+    }
     __device__ __forceinline__ bool cont(const State& s) const {
         return s.kk < c.iter_max && s.alpha > MPC_IPM_ALPHA_MIN && s.open && !s.declined;
     }

@@ -1418,6 +1418,57 @@ struct Wave2 : Algebra {
     __device__ __forceinline__ bool cont(const State& st) const {
         return st.kk < c.iter_max && st.alpha > K::alpha_min && st.open && !st.declined;
     }
+    // Mem::IPM (rti_core.hpp): a scan kernel parks the interior-point iterate of an instance it declines
+    // — the declined iteration has changed nothing — and the list kernel carries on from that iteration
+    // with the sequential recursions.  `slot`: the instance's record, (N + 1) stages of MPC_IPM_STAGE
+    // doubles (z 5, pi 3, lam 8, t 8) + the head {iterations done, last step length, diag bits}.
+    __device__ __forceinline__ void save_ipm(double* slot, const State& st) const {
+        double pi[2][3];
+        get_pi(pi);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const Stg& t = s[e];
+            if (!t.act) continue;
+            double* r = slot + (size_t)(2 * k + e) * MPC_IPM_STAGE;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) r[q] = t.z[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[5 + q] = pi[e][q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { r[8 + q] = t.bn.lam[q]; r[16 + q] = t.bn.t[q]; }
+        }
+        if (k == 0) {
+            double* hd = slot + (size_t)(N + 1) * MPC_IPM_STAGE;
+            hd[0] = (double)st.kk; hd[1] = st.alpha; hd[2] = (double)st.diag;
+        }
+    }
+    // after linearize() + cold_start(): replace the cold iterate by the parked one and take up the count
+    __device__ __forceinline__ void load_ipm(const double* slot, State& st) {
+        double pi[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            Stg& t = s[e];
+            const int j = 2 * k + e;
+            const double* r = slot + (size_t)(j <= N ? j : N) * MPC_IPM_STAGE;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) t.z[q] = t.act ? r[q] : t.z[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pi[e][q] = t.mid ? r[5 + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool hb = has_bound(t, q & 3);
+                const double tq = hb ? r[16 + q] : 1.0;
+                t.bn.lam[q] = hb ? r[8 + q] : 0.0;
+                t.bn.t[q] = tq;
+                t.ti[q] = hb ? rcp(tq) : 1.0;
+            }
+        }
+        set_pi(pi);
+        bu(st.musum, st.open);
+        st.mu = st.musum * nc_inv();
+        const double* hd = slot + (size_t)(N + 1) * MPC_IPM_STAGE;
+        st.kk = (int)hd[0]; st.alpha = hd[1]; st.diag = (int)hd[2];
+    }
     // The search direction of one IPM iteration (OCP_QP_IPM_DELTA_STEP) and, if it is accepted,
     // the variable update.  US: with the parallel scans; the stationarity residual of the linear
     // system (lin_g, what HPIPM's refinement loop tests against 1e-6) is then checked against
@@ -1431,8 +1482,13 @@ struct Wave2 : Algebra {
         if (US) {
             factor_now<US>();
         } else {
+#ifdef MPC_AB_NO_LQ
+            factor_now<false>(false);
+            if (false) {
+#else
             factor_now<false>(st.force_lq);
-            if (!st.force_lq && lq_wanted_seq()) {   // HPIPM lq_fact = 1: switch to the LQ factorisation
+            if (!st.force_lq && lq_wanted_seq()) {
+#endif   // HPIPM lq_fact = 1: switch to the LQ factorisation
                 st.force_lq = true;
                 st.diag |= MPC_DIAG_LQ;
                 factor_now<false>(true);

@@ -891,8 +891,10 @@ def test_chunked_host_solve_with_declined_instances():
     """A host-pointer solve large enough to be pipelined in chunks (two here), on a workload where
     the scan kernel declines about one instance in ten: every chunk has its own scan + list launch
     pair on a slice of the handle's arrays and the list holds slice-relative indices.  Against the
-    sequential model on the same inputs: everything within 1e-9, and the declined instances — solved
-    by the very same sequential kernel — bit for bit."""
+    sequential model on the same inputs: same status and iteration counts everywhere, 1e-9 on the
+    instances the scan kernel solved; the declined ones carry on in the list kernel from the iteration
+    the scan kernel could not certify (Mem::IPM), so their first iterations are scan arithmetic on
+    exactly the ill-conditioned QPs: 1e-8 (measured 1.5e-9), against the 1e-6 bar."""
     B = 32768 + 37
     sp, wl = workload.make("mobile_robot", B)
     x0, yref, yref_e = (a.copy() for a in wl.tick(0))
@@ -912,9 +914,10 @@ def test_chunked_host_solve_with_declined_instances():
     assert 0.02 * B < declined.sum() < 0.5 * B and ((ds & 4) == 0).all()
     for lo, hi in ((0, 16448), (16448, B)):     # both chunks took part
         assert declined[lo:hi].any()
+    assert np.array_equal((da & 16) != 0, declined)   # every declined instance carried on from its parked iterate
     assert np.array_equal(ra["status"], rs["status"]) and np.array_equal(ra["qp_iter"], rs["qp_iter"])
-    assert np.abs(ua - us).max() < TOL_PATH and np.abs(ra["u0"] - rs["u0"]).max() < TOL_PATH
-    assert np.array_equal(ua[declined], us[declined]) and np.array_equal(ra["u0"][declined], rs["u0"][declined])
+    assert np.abs(ua - us)[~declined].max() < TOL_PATH and np.abs(ra["u0"] - rs["u0"])[~declined].max() < TOL_PATH
+    assert np.abs(ua - us)[declined].max() < 10 * TOL_PATH and np.abs(ra["u0"] - rs["u0"])[declined].max() < 10 * TOL_PATH
 
 
 @pytest.mark.parametrize("B", [3000, 40000])
@@ -1314,14 +1317,16 @@ def test_two_shards_equal_one(oracle, cap):
 
 
 def test_wave_only_handle_owns_little_more_than_its_capsules():
-    """A handle that only runs the wave model holds the capsules (64 B per stage) and the small
-    per-instance arrays; the lane model's workspace and the host-pointer staging appear on first use."""
+    """A handle that only runs the wave model holds the capsules (64 B per stage), the records in
+    which declined instances park their interior-point iterate for the list kernel (192 B per stage;
+    RTI handles, Mem::IPM) and the small per-instance arrays; the lane model's workspace and the
+    host-pointer staging appear on first use."""
     torch = pytest.importorskip("torch")
     B = 65536
     sp, wl = workload.make("mobile_robot", B)
     solver = capi.BatchSolver(sp, B)
-    cap_bytes = B * (sp.N + 1) * 64
-    assert cap_bytes <= solver.device_bytes() < cap_bytes * 1.05          # 0.214 GB
+    cap_bytes = B * (sp.N + 1) * (64 + 192) + B * 64
+    assert cap_bytes <= solver.device_bytes() < cap_bytes * 1.05          # 0.214 GB of capsules + 0.65 GB of records
     x0, yref, yref_e = wl.tick(0)
     dev = torch.device("cuda:0")
     d = [torch.from_numpy(a).to(dev) for a in (x0, yref, yref_e)]

@@ -2,6 +2,8 @@
 device array of the library) — against mpc_batch_solve_device on a handle, through the C-ABI:
 same kernels, so the outputs are compared bit for bit (the bar is north_star's 1e-6).  Two calls
 in a row, the second with a smaller batch; cold and warm semantics; size limits."""
+import os
+
 import numpy as np
 import pytest
 
@@ -134,7 +136,9 @@ def test_static_call_captured_in_a_graph_replays_like_a_handle():
     in ten, so every replay goes through the list of declined instances and the sequential kernel
     behind it; which of the two list counters a solve uses is device state (Mem::REDO), so a replay
     counts from zero like a fresh call.  Against a handle making the same calls: bit for bit, three
-    replays in a row."""
+    replays in a row.  (The handle is created with MPC_RESUME=0: like the static array it then has no
+    records for the interior-point iterates of declined instances, and its list kernel solves them from
+    the cold start as the entry point's does.)"""
     torch = pytest.importorskip("torch")
     B = 4000   # 2000 sets of two instances: more than the chip's 1024 wavefront slots, i.e. the persistent scan kernel,
     #            whose work counter must put itself back to zero for the next replay
@@ -144,7 +148,15 @@ def test_static_call_captured_in_a_graph_replays_like_a_handle():
     x0[:, :2] -= shift; yref[:, :, :2] -= shift[:, None, :]; yref_e[:, :2] -= shift
     sp = sp.copy(lbx=(-0.3, -0.3), ubx=(0.3, 0.3), W=tuple(1e4 * w for w in sp.W), W_e=tuple(1e4 * w for w in sp.W_e))
     d = [_dev(torch, a) for a in (x0, yref, yref_e)]
-    handle = capi.BatchSolver(sp, B, devices=[0])
+    keep = os.environ.get("MPC_RESUME")
+    os.environ["MPC_RESUME"] = "0"
+    try:
+        handle = capi.BatchSolver(sp, B, devices=[0])
+    finally:
+        if keep is None:
+            del os.environ["MPC_RESUME"]
+        else:
+            os.environ["MPC_RESUME"] = keep
     ref, declined = [], 0
     for r in range(4):
         u0, st, it = _outs(torch, B)
