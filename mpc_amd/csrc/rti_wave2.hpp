@@ -1021,13 +1021,24 @@ struct Wave2 : Algebra {
         bool redo_centering;
         bool accepted;
     };
+    // `pre`: (sequential predictor only) the forward sweep has been made already — by the LQ test on the
+    // affine direction, direction() — and its result is passed in
+    struct Sweep { double nx[2][3], dl[2][5]; };
     template <bool FINAL, bool US>
     __device__ __forceinline__ void fw(int mode, double sigma_mu, FwdOut& o, double musum = 0.0, double mu_aff0 = 0.0,
-                                       bool may_retry = false) {
+                                       bool may_retry = false, const Sweep* pre = nullptr) {
         double nx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         double dl[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
         if (US) fwd_scan(nx, dl);
-        else fwd_seq_ipm(nx, dl);
+        else if (pre) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nx[e][q] = pre->nx[e][q];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dl[e][q] = pre->dl[e][q];
+            }
+        } else fwd_seq_ipm(nx, dl);
         double ginv = 1.0;
         double dn = 1.0, dd = -1.0;
         double s1 = 0.0, s2 = 0.0, lin_g = 0.0;
@@ -1382,10 +1393,20 @@ struct Wave2 : Algebra {
     // HPIPM's lq_fact = 1 test (OCP_QP_IPM_DELTA_STEP): the residual of the linearised KKT system at the
     // AFFINE direction the regular factorisation has just produced; any of its four inf-norms above
     // 1e-5 -> refactorise with LQ and stay with LQ for the rest of this QP.  Sequential path only.
-    __device__ __forceinline__ bool lq_wanted_seq() const {
-        double nx[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        double dz[2][5] = {{0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0}};
-        fwd_seq_ipm(nx, dz);
+    // (`w`: the affine direction's forward sweep, which the predictor then uses as it is)
+    __device__ __forceinline__ void affine_sweep_seq(Sweep& w) const {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w.nx[e][q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) w.dl[e][q] = 0.0;
+        }
+        fwd_seq_ipm(w.nx, w.dl);
+    }
+    __device__ __forceinline__ bool lq_wanted_seq(const Sweep& w) const {
+        const double (&nx)[2][3] = w.nx;
+        const double (&dz)[2][5] = w.dl;
         Con cq[2][4];
         Step sp[2][4];
         const Opq oq = opq();
@@ -1479,24 +1500,24 @@ struct Wave2 : Algebra {
         long long t0 = 0, t1 = 0;
         (void)t0; (void)t1;
         MPC_PH(0, t0, t0);   // (starts the clock: adds 0)
+        FwdOut fa;
         if (US) {
             factor_now<US>();
+            MPC_PH(0, t0, t1);   // factorisation scan + first right-hand side
+            fw<false, US>(0, 0.0, fa);
         } else {
-#ifdef MPC_AB_NO_LQ
-            factor_now<false>(false);
-            if (false) {
-#else
+            Sweep aff;   // the affine direction: tested for the LQ switch, then used by the predictor
             factor_now<false>(st.force_lq);
-            if (!st.force_lq && lq_wanted_seq()) {
-#endif   // HPIPM lq_fact = 1: switch to the LQ factorisation
+            affine_sweep_seq(aff);
+            if (!st.force_lq && lq_wanted_seq(aff)) {   // HPIPM lq_fact = 1: switch to the LQ factorisation
                 st.force_lq = true;
                 st.diag |= MPC_DIAG_LQ;
                 factor_now<false>(true);
+                affine_sweep_seq(aff);
             }
+            MPC_PH(0, t0, t1);
+            fw<false, false>(0, 0.0, fa, 0.0, 0.0, false, &aff);
         }
-        MPC_PH(0, t0, t1);   // factorisation scan + first right-hand side
-        FwdOut fa;
-        fw<false, US>(0, 0.0, fa);
         MPC_PH(1, t1, t0);   // predictor forward pass
         const double a_aff = fa.alpha;
         const double mu_aff0 = (st.musum + a_aff * fa.s1 + (a_aff * a_aff) * fa.s2) * nci;
