@@ -851,6 +851,13 @@ def test_lq_refactorisation_is_performed_on_the_device(oracle):
             assert glq.sum() >= 0.5 * lq.sum() and both >= 0.6 * glq.sum(), (model, t, int(lq.sum()), int(glq.sum()), both)
             if model != "wave2seq":
                 assert ((dg & 4) != 0)[glq].all(), model      # LQ is performed by the list kernel
+            # the scan kernels (one and two stages per lane) park the iterate of a declined instance and the
+            # list kernel carries on from it (bit 16); the lane model hands over without one
+            handed = (dg & 4) != 0
+            if model in ("auto", "wave1"):
+                assert handed.any() and np.array_equal((dg & 16) != 0, handed), model
+            else:
+                assert ((dg & 16) == 0).all(), model
         xo, uo = ro["xtraj"], ro["utraj"]
     assert lq_oracle > 300, "the workload no longer makes the oracle take the LQ branch"
     for s in solvers.values():
