@@ -240,6 +240,7 @@ def main():
             if ex:
                 roof["executed_achieved"] = ex / (l_ms * 1e-3) / 1e12
                 roof["executed_frac"] = roof["executed_achieved"] / FP64_VECTOR_PEAK_TFLOPS
+                roof["executed_over_algorithmic"] = ex / flops_launch   # (the dense count of `frac`)
             roof["counters_from"] = {"file": os.path.relpath(PROFILE_SUMMARY, ROOT), "commit": prof.get("commit"),
                                      "kernel_source_sha": prof.get("kernel_source_sha"), "stale": prof["stale"]}
         out["roofline"] = roof
