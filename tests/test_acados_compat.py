@@ -244,3 +244,42 @@ def test_c_caller_through_the_acados_names_equals_mpc_batch_and_oracle(oracle, n
     assert rd.i == len(rd.a), "unread output"
     assert "qp_iter" in r.stdout          # <name>_acados_print_stats
     assert r.stderr.count("acados_compat") == 3
+
+
+EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "examples")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(EXAMPLES, "main_mobile_robot")),
+                    reason="oracle/_ref/examples not built (make -C oracle where the reference tree is mounted)")
+@pytest.mark.parametrize("name", sorted(REF_DIR))
+def test_reference_example_programs_run_on_the_gpu(oracle, name):
+    """The reference's OWN generated example programs — src/c_generated_code*/main_<name>.c (create with
+    discretisation, x0 through lbx/ubx, initial iterate through ocp_nlp_out_set, rti_phase, solve, time_tot,
+    trajectories through ocp_nlp_out_get, print_stats, free) and main_sim_<name>.c (three integrator steps) —
+    compiled unmodified in the build container (oracle/Makefile: ref_examples) against include/acados_compat
+    and libmpc_amd.so, run here.  They must report success, and the trajectories they print must be the
+    oracle's for the same problem (x0 = 0, the generated yref = 0, zero iterate) to the printed precision."""
+    sp = variants.spec(name)
+    N = sp.N
+    r = subprocess.run([os.path.join(EXAMPLES, f"main_{name}")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    out = r.stdout
+    assert f"{name}_acados_solve(): SUCCESS!" in out and "SQP iterations  1" in out
+    body = out.split("--- xtraj ---")[1]
+    xs, us = body.split("--- utraj ---")
+    us = us.split("solved ocp")[0]
+    xt = np.array([float(t) for t in xs.split()]).reshape(N + 1, 3)
+    ut = np.array([float(t) for t in us.split()]).reshape(N, 2)
+    ro = oracle.rti_batch(sp, np.zeros((1, 3)), np.zeros((1, N, 5)), np.zeros((1, 3)))
+    assert ro["status"][0] == 0
+    assert np.abs(xt - ro["xtraj"][0]).max() < 1e-6 and np.abs(ut - ro["utraj"][0]).max() < 1e-6
+    m = re.search(r"minimum time for 1 solve ([0-9.]+) \[ms\]", out)
+    assert m and 0.0 < float(m.group(1)) < 1000.0
+    # the integrator example: three steps from x = 0 with u = 0 stay at 0
+    r = subprocess.run([os.path.join(EXAMPLES, f"main_sim_{name}")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "Performed 3 simulation steps with acados integrator successfully." in r.stdout
+    vals = [float(t) for blk in r.stdout.split("x_current,")[1:] for t in blk.split("\n")[1:4]]
+    assert len(vals) == 9 and max(abs(v) for v in vals) == 0.0
+
