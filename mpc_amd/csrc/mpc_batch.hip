@@ -1685,8 +1685,9 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
         return 0;
     }
     // enqueue on every shard, then wait for all.  (Copies from pageable host memory are staged by
-    // the runtime and serialise with the host; callers that want the shards' copies to overlap
-    // pass pinned arrays — hipHostMalloc / hipHostRegister — or use one handle per device.)
+    // the runtime and serialise with the host; callers that want the shards' transfers to overlap
+    // pass pinned arrays — hipHostMalloc / hipHostRegister: read in place, below — or use one
+    // handle per device.)
     auto body = [&]() -> int {
         for (Shard& s : h->shards) {
             const int n = B - s.first < s.cap ? B - s.first : s.cap;
@@ -1695,11 +1696,14 @@ int mpc_batch_solve(mpc_batch_t* h, int B, const double* x0, const double* yref,
             HIPCHK(h, hipSetDevice(s.device));
             int rc = 0;
             const int model = pick_model(h);
-            // Pinned caller arrays (single-device handles): no staging at all — the wave kernels read
-            // x0 / yref / yref_e from the caller's memory over the host link while they compute (2 KB
-            // per instance at its start, 23 GB/s at the headline rate) and write u0 straight back.
+            // Pinned caller arrays: no staging at all — the wave kernels read x0 / yref / yref_e from
+            // the caller's memory over the host link while they compute (2 KB per instance at its
+            // start, 23 GB/s at the headline rate) and write u0 straight back.  Handles with several
+            // devices: every shard asks for the arrays' address under its own device (pinned host
+            // memory is mapped into every device's address space on ROCm) and reads its own slice, so
+            // the shards' transfers overlap instead of queueing behind staged copies.
             const double* px0 = nullptr; const double* pyref = nullptr; const double* pyrefe = nullptr;
-            if (h->shards.size() == 1 && model != MPC_MODEL_LANE && !xtraj) {
+            if (model != MPC_MODEL_LANE && !xtraj) {
                 px0 = pinned_device_ptr(x0, 3 * (size_t)B); pyref = pinned_device_ptr(yref, 5 * (size_t)N * B); pyrefe = pinned_device_ptr(yref_e, 3 * (size_t)B);
             }
             if (px0 && pyref && pyrefe) {

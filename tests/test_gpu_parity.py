@@ -953,7 +953,19 @@ def test_pinned_caller_arrays_are_read_in_place(B):
     assert direct.device_bytes() + 2000 * B <= staged.device_bytes()
     g1, g2 = staged.get(B), direct.get(B)
     assert all(np.array_equal(a, b) for a, b in zip(g1, g2))
-    staged.close(); direct.close()
+    # a handle with several shards (the one-GPU box gives both device 0): each shard reads its own
+    # slice of the pinned arrays in place; forced to one kernel, bit for bit with a staged two-shard handle
+    two_staged, two_direct = capi.BatchSolver(sp, B, devices=[0, 0]), capi.BatchSolver(sp, B, devices=[0, 0])
+    two_staged.set_model("wave2"); two_direct.set_model("wave2")
+    for t in range(2):
+        arrs = [np.ascontiguousarray(a) for a in wl.tick(t)]
+        keep = [torch.from_numpy(a.copy()).pin_memory() for a in arrs]
+        r1 = two_staged.solve(*arrs)
+        r2 = two_direct.solve(*[k.numpy() for k in keep])
+        for k in ("u0", "status", "qp_iter"):
+            assert np.array_equal(r1[k], r2[k]), (t, k)
+    assert two_direct.device_bytes() + 2000 * B <= two_staged.device_bytes()
+    staged.close(); direct.close(); two_staged.close(); two_direct.close()
 
 
 def test_diag_is_clean_on_the_bench_workload():
